@@ -1,0 +1,217 @@
+/*
+ * s2i_hip.h — C-ABI of the MI355X (gfx950) kernels under the StackGAN-v2 G/D train step.
+ *
+ * The reference (smallflyingpig/speech-to-image-translation-without-text) has no FFI of its own:
+ * its hot path is stock torch.nn modules (StackGAN_v2/model.py:112-551) driven by
+ * StackGAN_v2/trainer.py:375-489.  Each entry point below replaces one group of torch ops on that
+ * path; the reference site it stands in for is cited next to it.  The Python host
+ * (speech_to_image_translation_without_text_amd/ops.py) binds these with ctypes.
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer, borrowed for the stream-ordered duration of the call;
+ *   - nothing here allocates, frees or synchronises; scratch comes in through (ws, ws_bytes);
+ *   - every call returns 0 on success; on failure a non-zero code, and s2i_last_error() holds text;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - activations are NHWC fp32, channel counts multiples of 4, spatial extents powers of two;
+ *   - conv weights are consumed in the packed layout P[tap][Cin][Coutp] (Coutp = Cout rounded up
+ *     to 4) written by s2i_pack_conv_weight from the reference's OIHW parameter tensors.
+ */
+#ifndef S2I_HIP_H
+#define S2I_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2I_ABI_VERSION 1
+
+/* conv geometry kinds */
+#define S2I_CONV_K1      0  /* 1x1 / nn.Linear (model.py:179, 217)                              */
+#define S2I_CONV_K3S1    1  /* conv3x3 pad 1 (model.py:125-128)                                 */
+#define S2I_CONV_K4S2    2  /* Conv2d(k4,s2,p1) (model.py:371, 383-394); also dgrad of upBlock  */
+#define S2I_TCONV_K4S2   3  /* 4-phase transposed conv k4 s2 p1: nearest x2 + conv3x3 collapsed
+                               (model.py:133-140) and dgrad of Conv2d(k4,s2,p1)                 */
+
+/* activations */
+#define S2I_ACT_NONE     0
+#define S2I_ACT_GLU      1  /* model.py:112-122 */
+#define S2I_ACT_LRELU    2  /* nn.LeakyReLU(0.2), model.py:363, 373 */
+#define S2I_ACT_TANH     3  /* model.py:293 */
+
+/* weight pack modes */
+#define S2I_PACK_PLAIN   0  /* P[t][i][o] = W[o][i][t]                                          */
+#define S2I_PACK_UPFOLD  1  /* 3x3 -> effective 4x4 taps of nearest-x2 + conv3x3               */
+
+const char* s2i_last_error(void);
+int  s2i_version(void);
+/* 0 when the current device is gfx950, non-zero (and last_error set) otherwise */
+int  s2i_check_device(void);
+
+/* ---- implicit-GEMM convolution (fp32 MFMA v_mfma_f32_32x32x2_f32) ------------------------- */
+typedef struct s2i_conv_desc {
+  int kind;      /* S2I_CONV_* / S2I_TCONV_K4S2                                                  */
+  int B, H, W;   /* batch and spatial extent of the GATHERED tensor x                           */
+  int Cx;        /* channels stored in x                                                        */
+  int Cc;        /* channels of a per-image vector broadcast over space and concatenated FIRST
+                    (torch.cat((c_code, h_code), 1), model.py:277, 434); 0 = none               */
+  int N;         /* output channels                                                             */
+  int wmode;     /* 0: weights used as P[t][k][n];  1: transposed per tap, P[t][n][k] (dgrad)    */
+  int flip;      /* 1: tap t reads P[T-1-t] (dgrad of a stride-1 3x3)                            */
+  int wR;        /* rows per tap in P                                                           */
+  int ldw;       /* row stride of P (= Coutp of the forward layer)                              */
+  int act;       /* epilogue: S2I_ACT_NONE / LRELU / TANH                                        */
+  int stats;     /* 1: also emit per-row-tile column sums and sums of squares (BatchNorm)       */
+  int ldy;       /* row stride of y                                                             */
+} s2i_conv_desc;
+
+/* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */
+size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d);
+/* number of partial rows the stats epilogue writes: part is [2][nparts][N] floats */
+int    s2i_conv_stat_parts(const s2i_conv_desc* d);
+/*
+ * y[row][n] = act( sum_{t,c} X(row,t,c) * Wt[t][c][n] + bias[n] )
+ * X gathers x (and cvec) per `kind`; rows enumerate (b,oy,ox) of the output grid.
+ * Replaces F.conv2d / F.linear forward and their input-gradient on the reference path.
+ */
+int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                     const float* bias, float* y, float* part, void* ws, size_t ws_bytes,
+                     void* stream);
+
+/* ---- weight gradient ------------------------------------------------------------------------ */
+typedef struct s2i_wgrad_desc {
+  int kind;      /* geometry of the gather applied to `a`                                        */
+  int B, H, W;   /* extent of the gathered tensor a                                             */
+  int Ca;        /* channels stored in a                                                        */
+  int Cc;        /* broadcast-vector channels concatenated first (0 = none)                     */
+  int N;         /* channels of the plain (un-gathered) operand g                               */
+  int ldg;       /* row stride of g                                                             */
+  int swap;      /* 0: result rows (tap,cin) x cols cout;  1: rows (tap,cout) x cols cin        */
+  int fold;      /* 1: fold effective 4x4 taps back onto the 3x3 parameter (S2I_PACK_UPFOLD)    */
+  int O, I, KH, KW; /* shape of the OIHW gradient tensor written                                */
+  int accumulate;   /* 1: grad += result, 0: grad = result                                      */
+} s2i_wgrad_desc;
+
+size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);
+/*
+ * grad_oihw (+)= sum_rows A(row,t,c) * g[row][n]   — the weight-gradient of F.conv2d / F.linear
+ * (autograd of model.py:125-128, 179, 217, 371, 383-394), written straight into the reference's
+ * OIHW parameter layout.
+ */
+int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
+                   float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+
+/* OIHW parameter -> packed P[t][Ip][Op] (Ip >= I, Op = O rounded up to 4; padding zero filled) */
+int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int KH, int KW,
+                         int Ip, int mode, void* stream);
+
+/* ---- BatchNorm (training statistics) + activation ------------------------------------------ */
+/*
+ * Reduce the conv epilogue's partials to batch statistics (nn.BatchNorm2d/1d in training mode,
+ * model.py:137, 147, 158, 161, 218, 361, 372): mean, biased var -> invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale; running_mean/var updated with momentum (unbiased var), as torch does.
+ * out4 = [mean | invstd | scale | shift], each C floats.
+ */
+int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum,
+                    float eps, float* out4, void* stream);
+/* eval-mode BatchNorm: scale/shift from the running statistics (trainer.py:681-803 path) */
+int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* out4, void* stream);
+/*
+ * out = act(scale*y + shift) (+ residual).  GLU halves the channel count (C -> C/2).
+ * Replaces BatchNorm apply + GLU / LeakyReLU / ResBlock add (model.py:116-122, 165-169).
+ */
+int s2i_bn_act_forward(const float* y, long long M, int C, const float* coef4, int act,
+                       const float* residual, float* out, void* stream);
+/* column sums of the raw tensor when no conv epilogue produced them: part = [2][nparts][C] */
+int s2i_colstats(const float* y, long long M, int C, int ldy, float* part, int nparts,
+                 void* stream);
+/*
+ * Backward of bn_act_forward, pass 1: per-channel sums of dz and dz*xhat (dz = gradient w.r.t. the
+ * BatchNorm output after un-doing the activation).  part = [2][nparts][C].
+ */
+int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int C,
+                          const float* coef4, int act, float* part, int nparts, void* stream);
+/* finalise pass 1: dgamma, dbeta (accumulated or assigned) and the two means for pass 2.
+   red2 = [mean_dz | mean_dz_xhat], each C floats. */
+int s2i_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+                        float* dbeta, int accumulate, float* red2, void* stream);
+/* pass 2: dy = scale * (dz - mean_dz - xhat*mean_dz_xhat) */
+int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int C,
+                         const float* coef4, const float* red2, int act, float* dy, void* stream);
+
+/* ---- plain activations ---------------------------------------------------------------------- */
+/* dy = dout * act'(out) for LRELU / TANH given the forward OUTPUT (sign- / value-recoverable) */
+int s2i_act_backward(const float* out, const float* dout, int lddout, long long M, int C, int act,
+                     float* dy, void* stream);
+/* 2-D GLU without BatchNorm (CA_NET, model.py:183): out[M][C/2] */
+int s2i_glu_forward(const float* x, long long M, int C, float* out, void* stream);
+int s2i_glu_backward(const float* x, const float* dout, long long M, int C, float* dx,
+                     void* stream);
+
+/* ---- layout ---------------------------------------------------------------------------------- */
+/* NCHW (C channels) -> NHWC with Cp >= C channels (extra channels zero), and back */
+int s2i_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cp,
+                     void* stream);
+int s2i_nhwc_to_nchw(const float* src, int lds, float* dst, int B, int C, int H, int W,
+                     void* stream);
+/* sum over the H*W rows of each image of the first C columns of a [B*HW][ld] tensor -> [B][C] */
+int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, float* dst, void* ws,
+                    size_t ws_bytes, void* stream);
+size_t s2i_spatial_sum_workspace_bytes(int B, int HW, int C);
+
+/* ---- CA_NET reparameterisation + KL (model.py:182-200, trainer.py:54-58) -------------------- */
+/* h = GLU output [B][2E] = [mu | logvar];  c = eps*exp(0.5*logvar) + mu */
+int s2i_reparam_forward(const float* h, const float* eps, int B, int E, float* c, void* stream);
+/* dh[:, :E] = dc + dmu_extra ; dh[:, E:] = dc*eps*0.5*exp(0.5*logvar) + dlogvar_extra */
+int s2i_reparam_backward(const float* h, const float* eps, const float* dc, const float* dmu,
+                         const float* dlogvar, int B, int E, float* dh, void* stream);
+/* kl = -0.5*mean(1 + logvar - mu^2 - exp(logvar));  also the gradient scaled by `gscale` */
+int s2i_kl_forward(const float* mu, int ldmu, const float* logvar, int ldlv, int B, int E,
+                   float* kl, void* stream);
+int s2i_kl_backward(const float* mu, int ldmu, const float* logvar, int ldlv, int B, int E,
+                    const float* gout, float* dmu, float* dlogvar, void* stream);
+
+/* ---- logit heads: Conv2d(C,1,k=4,s=4)+Sigmoid on a 4x4 map (model.py:414-422) + BCE --------- */
+/* x NHWC [B][16][C]; w OIHW [1][C][4][4]; prob[b] = sigmoid(<x_b,w> + bias) */
+int s2i_logit_forward(const float* x, const float* w, const float* bias, int B, int C,
+                      float* prob, void* stream);
+/* dlogit[b] given dprob; dx (+)= dlogit*w ; dw (+)= sum_b dlogit*x ; dbias (+)= sum dlogit */
+int s2i_logit_backward(const float* x, const float* w, const float* prob, const float* dprob,
+                       int B, int C, float* dx, int acc_dx, float* dw, float* dbias, int acc_dw,
+                       void* stream);
+/* nn.BCELoss(mean) with torch's log clamp at -100 (trainer.py:394-409, 439-443):
+   loss (+)= weight * mean(-(t*log p + (1-t)*log(1-p))) ; dprob = weight*gout * dL/dp */
+int s2i_bce_forward(const float* prob, float target, int B, float weight, float* loss,
+                    int accumulate, void* stream);
+int s2i_bce_backward(const float* prob, float target, int B, float weight, const float* gout,
+                     float* dprob, void* stream);
+
+/* ---- class-aware loss (trainer.py:298-311) ------------------------------------------------------ */
+/* scores = X X^T [B][B] (from s2i_conv_forward, K1, wmode 1); labels int32 [B];
+   loss = max(0, mean(S) - mean(S[same class, off-diagonal])) / D, 0 when no such pair.
+   dscores = d loss / d S (so that dX = (dS + dS^T) X), both scaled by nothing: caller scales. */
+int s2i_cal_loss(const float* scores, const int* labels, int B, int D, float* loss, int accumulate,
+                 float* dscores_sym, void* stream);
+
+/* ---- optimiser (trainer.py:236-252, 571-572) -------------------------------------------------- */
+/* torch.optim.Adam (no weight decay, no amsgrad) on a flat buffer, step = 1-based step count */
+int s2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                  float beta2, float eps, int step, const int* step_dev, float gscale, void* stream);
+/* *counter += 1 on the stream (device-resident Adam step count, so a captured hipGraph of the
+   train step replays with the right bias correction) */
+int s2i_increment(int* counter, void* stream);
+/* avg = decay*avg + (1-decay)*p */
+int s2i_ema_update(float* avg, const float* p, long long n, float decay, void* stream);
+/* y = x * a_dev[0] (the scalar lives on the device: no host synchronisation) */
+int s2i_scale_dev(float* y, const float* x, long long n, const float* a_dev, void* stream);
+/* y = a*x (+ y) elementwise helpers used for gradient averaging and accumulation */
+int s2i_axpby(float* y, const float* x, long long n, float a, float b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2I_HIP_H */

@@ -1,0 +1,848 @@
+// HBM-bound kernels of the StackGAN-v2 step on gfx950: BatchNorm statistics/apply fused with
+// GLU / LeakyReLU / residual add, their backward passes (two per-channel reductions + apply),
+// layout conversion, CA_NET reparameterisation + KL, logit heads + BCE, class-aware loss,
+// fused Adam / EMA.  All tensors NHWC fp32; every thread moves float4 (16 B/lane).
+#include "s2i_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// thread layout for per-channel reductions over the rows of an [M][C] tensor:
+// `cpb` threads across channel quads, 256/cpb row lanes.
+struct RedGeom {
+  int Q, cpb, rpb, gy;
+};
+static RedGeom red_geom(int C) {
+  RedGeom g;
+  g.Q = C / 4;
+  int cpb = 1;
+  while (cpb < g.Q && cpb < 256) cpb <<= 1;
+  g.cpb = cpb;
+  g.rpb = 256 / cpb;
+  g.gy = (g.Q + cpb - 1) / cpb;
+  return g;
+}
+
+// ---- per-quad value functors ------------------------------------------------------------------
+// dz for BN-channel quad `quad` at `row`, un-doing the activation that followed BatchNorm
+__device__ __forceinline__ f32x4 act_dz(const float* __restrict__ y, const float* __restrict__ dout, int lddout,
+                                        long long row, int C, int quad, const float* __restrict__ coef,
+                                        int act, f32x4 yv) {
+  const float* scale = coef + 2 * C;
+  const float* shift = coef + 3 * C;
+  f32x4 dz;
+  if (act == S2I_ACT_GLU) {
+    const int hq = C / 8;  // quads per half
+    const bool first = quad < hq;
+    const int pq = first ? quad + hq : quad - hq;
+    const f32x4 yp = ld4(y + row * C + pq * 4);
+    const f32x4 d = ld4(dout + row * lddout + (first ? quad : pq) * 4);
+    const f32x4 sa = ld4(scale + (first ? quad : pq) * 4), ta = ld4(shift + (first ? quad : pq) * 4);
+    const f32x4 sg = ld4(scale + (first ? pq : quad) * 4), tg = ld4(shift + (first ? pq : quad) * 4);
+    const f32x4 ya = first ? yv : yp, yg = first ? yp : yv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float za = sa[j] * ya[j] + ta[j];
+      const float sgm = sigmoidf_(sg[j] * yg[j] + tg[j]);
+      dz[j] = first ? d[j] * sgm : d[j] * za * sgm * (1.f - sgm);
+    }
+  } else {
+    const f32x4 d = ld4(dout + row * lddout + quad * 4);
+    if (act == S2I_ACT_LRELU) {
+      const f32x4 sc = ld4(scale + quad * 4), sh = ld4(shift + quad * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dz[j] = (sc[j] * yv[j] + sh[j]) > 0.f ? d[j] : 0.2f * d[j];
+    } else {
+      dz = d;
+    }
+  }
+  return dz;
+}
+
+template <int MODE>  // 0: (y, y^2)   1: (dz, dz*xhat)
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y, int ldy,
+                                                        const float* __restrict__ dout, int lddout,
+                                                        long long M, int C, const float* __restrict__ coef,
+                                                        int act, float* __restrict__ part, int nparts, int cpb) {
+  __shared__ f32x4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.y * cpb + ql;
+  const int Q = C / 4;
+  const long long chunk = (M + nparts - 1) / nparts;
+  const long long r0 = (long long)blockIdx.x * chunk;
+  const long long r1 = r0 + chunk < M ? r0 + chunk : M;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (quad < Q) {
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, invstd = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) { mean = ld4(coef + quad * 4); invstd = ld4(coef + C + quad * 4); }
+    for (long long row = r0 + rl; row < r1; row += rpb) {
+      const f32x4 yv = ld4(y + row * ldy + quad * 4);
+      if (MODE == 0) {
+        s0 += yv;
+        s1 += yv * yv;
+      } else {
+        const f32x4 dz = act_dz(y, dout, lddout, row, C, quad, coef, act, yv);
+        s0 += dz;
+        s1 += dz * ((yv - mean) * invstd);
+      }
+    }
+  }
+  sh[0][tid] = s0;
+  sh[1][tid] = s1;
+  __syncthreads();
+  if (rl == 0 && quad < Q) {
+    for (int r = 1; r < rpb; ++r) {
+      s0 += sh[0][r * cpb + ql];
+      s1 += sh[1][r * cpb + ql];
+    }
+    st4(part + ((size_t)0 * nparts + blockIdx.x) * C + quad * 4, s0);
+    st4(part + ((size_t)1 * nparts + blockIdx.x) * C + quad * 4, s1);
+  }
+}
+
+// reduce [2][nparts][C] partials in double; 1024 threads: qpb quads x (1024/qpb) part lanes
+template <int MODE>  // 0: BN forward statistics   1: BN backward sums
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                           double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ rmean,
+                                                           float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ out, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate, int qpb) {
+  extern __shared__ double shd[];  // [2][1024][4]
+  const int tid = threadIdx.x;
+  const int lanes = 1024 / qpb;
+  const int ql = tid % qpb, pl = tid / qpb;
+  const int quad = blockIdx.x * qpb + ql;
+  const int Q = C / 4;
+  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+  if (quad < Q) {
+    for (int pi = pl; pi < nparts; pi += lanes) {
+      const f32x4 v0 = ld4(part + ((size_t)0 * nparts + pi) * C + quad * 4);
+      const f32x4 v1 = ld4(part + ((size_t)1 * nparts + pi) * C + quad * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a0[j] += v0[j]; a1[j] += v1[j]; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    shd[(0 * 1024 + tid) * 4 + j] = a0[j];
+    shd[(1 * 1024 + tid) * 4 + j] = a1[j];
+  }
+  __syncthreads();
+  if (pl == 0 && quad < Q) {
+    for (int r = 1; r < lanes; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] += shd[(0 * 1024 + r * qpb + ql) * 4 + j];
+        a1[j] += shd[(1 * 1024 + r * qpb + ql) * 4 + j];
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = quad * 4 + j;
+      if (MODE == 0) {
+        const double mean = a0[j] / count;
+        double var = a1[j] / count - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        out[c] = (float)mean;
+        out[C + c] = invstd;
+        out[2 * C + c] = sc;
+        out[3 * C + c] = beta[c] - (float)mean * sc;
+        if (rmean) {
+          const double unb = count > 1 ? var * count / (count - 1) : var;
+          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+      } else {
+        out[c] = (float)(a0[j] / count);
+        out[C + c] = (float)(a1[j] / count);
+        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a0[j] : (float)a0[j];
+        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a1[j] : (float)a1[j];
+      }
+    }
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rvar[c] + eps);
+  const float sc = gamma[c] * invstd;
+  out[c] = rmean[c];
+  out[C + c] = invstd;
+  out[2 * C + c] = sc;
+  out[3 * C + c] = beta[c] - rmean[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, long long M, int C,
+                                                         const float* __restrict__ coef, int act,
+                                                         const float* __restrict__ residual,
+                                                         float* __restrict__ out) {
+  const float* scale = coef + 2 * C;
+  const float* shift = coef + 3 * C;
+  const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
+  const int Qo = Cout / 4;
+  const long long total = M * Qo;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / Qo;
+    const int q = (int)(e - row * Qo);
+    f32x4 o;
+    if (act == S2I_ACT_GLU) {
+      const f32x4 ya = ld4(y + row * C + q * 4), yg = ld4(y + row * C + Cout + q * 4);
+      const f32x4 sa = ld4(scale + q * 4), ta = ld4(shift + q * 4);
+      const f32x4 sg = ld4(scale + Cout + q * 4), tg = ld4(shift + Cout + q * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (sa[j] * ya[j] + ta[j]) * sigmoidf_(sg[j] * yg[j] + tg[j]);
+    } else {
+      const f32x4 yv = ld4(y + row * C + q * 4);
+      const f32x4 sc = ld4(scale + q * 4), sh = ld4(shift + q * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = sc[j] * yv[j] + sh[j];
+        if (act == S2I_ACT_LRELU) z = z > 0.f ? z : 0.2f * z;
+        o[j] = z;
+      }
+      if (residual) o += ld4(residual + row * C + q * 4);
+    }
+    st4(out + row * Cout + q * 4, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ dout, int lddout,
+                                                               long long M, int C, const float* __restrict__ coef,
+                                                               const float* __restrict__ red2, int act,
+                                                               float* __restrict__ dy) {
+  const int Q = C / 4;
+  const long long total = M * Q;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / Q;
+    const int q = (int)(e - row * Q);
+    const f32x4 yv = ld4(y + row * C + q * 4);
+    const f32x4 dz = act_dz(y, dout, lddout, row, C, q, coef, act, yv);
+    const f32x4 mean = ld4(coef + q * 4), invstd = ld4(coef + C + q * 4), sc = ld4(coef + 2 * C + q * 4);
+    const f32x4 m0 = ld4(red2 + q * 4), m1 = ld4(red2 + C + q * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (yv[j] - mean[j]) * invstd[j];
+      o[j] = sc[j] * (dz[j] - m0[j] - xh * m1[j]);
+    }
+    st4(dy + row * C + q * 4, o);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                      int lddout, long long M, int C, int act,
+                                                      float* __restrict__ dy) {
+  const int Q = C / 4;
+  const long long total = M * Q;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / Q;
+    const int q = (int)(e - row * Q);
+    const f32x4 ov = ld4(out + row * C + q * 4);
+    const f32x4 d = ld4(dout + row * lddout + q * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (act == S2I_ACT_LRELU) o[j] = ov[j] > 0.f ? d[j] : 0.2f * d[j];
+      else if (act == S2I_ACT_TANH) o[j] = d[j] * (1.f - ov[j] * ov[j]);
+      else o[j] = d[j];
+    }
+    st4(dy + row * C + q * 4, o);
+  }
+}
+
+__global__ void glu_fwd_kernel(const float* __restrict__ x, long long M, int C, float* __restrict__ out) {
+  const int H = C / 2;
+  const long long total = M * H;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e - row * H);
+    out[e] = x[row * C + c] * sigmoidf_(x[row * C + H + c]);
+  }
+}
+
+__global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, long long M, int C,
+                               float* __restrict__ dx) {
+  const int H = C / 2;
+  const long long total = M * H;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / H;
+    const int c = (int)(e - row * H);
+    const float a = x[row * C + c];
+    const float sg = sigmoidf_(x[row * C + H + c]);
+    const float d = dout[e];
+    dx[row * C + c] = d * sg;
+    dx[row * C + H + c] = d * a * sg * (1.f - sg);
+  }
+}
+
+// ---- layout -----------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW,
+                                    int Cp) {
+  const long long total = (long long)B * HW * Cp;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % Cp);
+    const long long bp = e / Cp;
+    const int pix = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    dst[e] = c < C ? src[((long long)b * C + c) * HW + pix] : 0.f;
+  }
+}
+// image fast path: C = 3 -> Cp = 4, one pixel per thread
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int HW) {
+  const long long total = (long long)B * HW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int pix = (int)(e % HW);
+    const long long b = e / HW;
+    const float* s = src + b * 3 * HW + pix;
+    f32x4 v = {s[0], s[HW], s[2 * (long long)HW], 0.f};
+    st4(dst + e * 4, v);
+  }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int B, int C,
+                                    int HW) {
+  const long long total = (long long)B * C * HW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int pix = (int)(e % HW);
+    const long long bc = e / HW;
+    const int c = (int)(bc % C);
+    const long long b = bc / C;
+    dst[e] = src[(b * HW + pix) * lds + c];
+  }
+}
+
+// per-image column sums, two stages: [B][S][C] partials then the S-sum
+__global__ __launch_bounds__(256) void spatial_sum_stage1(const float* __restrict__ src, int ld, int HW, int C,
+                                                          int S, float* __restrict__ tmp, int cpb) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.z * cpb + ql;
+  const int Q = C / 4;
+  const int b = blockIdx.x, sidx = blockIdx.y;
+  const int chunk = (HW + S - 1) / S;
+  const int r0 = sidx * chunk, r1 = min(HW, r0 + chunk);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (quad < Q)
+    for (int r = r0 + rl; r < r1; r += rpb) acc += ld4(src + ((long long)b * HW + r) * ld + quad * 4);
+  sh[tid] = acc;
+  __syncthreads();
+  if (rl == 0 && quad < Q) {
+    for (int r = 1; r < rpb; ++r) acc += sh[r * cpb + ql];
+    st4(tmp + ((size_t)b * S + sidx) * C + quad * 4, acc);
+  }
+}
+__global__ void spatial_sum_stage2(const float* __restrict__ tmp, int B, int S, int C, float* __restrict__ dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, c = e - b * C;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += tmp[((size_t)b * S + s) * C + c];
+  dst[e] = v;
+}
+
+// ---- CA_NET ------------------------------------------------------------------------------------
+__global__ void reparam_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps, int B, int E,
+                                   float* __restrict__ c) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * E) return;
+  const int b = e / E, j = e - b * E;
+  const float mu = h[b * 2 * E + j], lv = h[b * 2 * E + E + j];
+  c[e] = eps[e] * __expf(0.5f * lv) + mu;
+}
+__global__ void reparam_bwd_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                   const float* __restrict__ dc, const float* __restrict__ dmu,
+                                   const float* __restrict__ dlv, int B, int E, float* __restrict__ dh) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * E) return;
+  const int b = e / E, j = e - b * E;
+  const float lv = h[b * 2 * E + E + j];
+  const float g = dc ? dc[e] : 0.f;
+  dh[b * 2 * E + j] = g + (dmu ? dmu[e] : 0.f);
+  dh[b * 2 * E + E + j] = g * eps[e] * 0.5f * __expf(0.5f * lv) + (dlv ? dlv[e] : 0.f);
+}
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, int ldmu,
+                                                     const float* __restrict__ lv, int ldlv, int B, int E,
+                                                     float* __restrict__ kl) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < B * E; e += 256) {
+    const int b = e / E, j = e - b * E;
+    const float m = mu[b * ldmu + j], l = lv[b * ldlv + j];
+    acc += 1.f + l - m * m - __expf(l);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) kl[0] = -0.5f * sh[0] / (float)(B * E);
+}
+__global__ void kl_bwd_kernel(const float* __restrict__ mu, int ldmu, const float* __restrict__ lv, int ldlv, int B,
+                              int E, const float* __restrict__ gout, float* __restrict__ dmu,
+                              float* __restrict__ dlv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * E) return;
+  const int b = e / E, j = e - b * E;
+  const float g = gout[0] * (-0.5f) / (float)(B * E);
+  dmu[e] = g * (-2.f * mu[b * ldmu + j]);
+  dlv[e] = g * (1.f - __expf(lv[b * ldlv + j]));
+}
+
+// ---- logit heads + BCE ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void logit_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int C,
+                                                        float* __restrict__ prob) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x;
+  const int n = 16 * C;
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int pix = e / C, c = e - pix * C;
+    acc += x[(size_t)b * n + e] * w[c * 16 + pix];
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prob[b] = sigmoidf_(sh[0] + (bias ? bias[0] : 0.f));
+}
+__global__ void logit_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                 const float* __restrict__ prob, const float* __restrict__ dprob, int B, int C,
+                                 float* __restrict__ dx, int acc_dx, float* __restrict__ dw,
+                                 float* __restrict__ dbias, int acc_dw) {
+  const int n = 16 * C;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) {
+    const int pix = e / C, c = e - pix * C;
+    const float wv = w[c * 16 + pix];
+    float gw = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float pr = prob[b];
+      const float dl = dprob[b] * pr * (1.f - pr);
+      const size_t off = (size_t)b * n + e;
+      gw += dl * x[off];
+      if (dx) dx[off] = acc_dx ? dx[off] + dl * wv : dl * wv;
+    }
+    if (dw) dw[c * 16 + pix] = acc_dw ? dw[c * 16 + pix] + gw : gw;
+  }
+  if (e == 0 && dbias) {
+    float gb = 0.f;
+    for (int b = 0; b < B; ++b) gb += dprob[b] * prob[b] * (1.f - prob[b]);
+    dbias[0] = acc_dw ? dbias[0] + gb : gb;
+  }
+}
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target, int B,
+                                                      float weight, float* __restrict__ loss, int accumulate) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float p = prob[b];
+    const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+    acc += -(target * lp + (1.f - target) * lq);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float v = weight * sh[0] / (float)B;
+    loss[0] = accumulate ? loss[0] + v : v;
+  }
+}
+__global__ void bce_bwd_kernel(const float* __restrict__ prob, float target, int B, float weight,
+                               const float* __restrict__ gout, float* __restrict__ dprob) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float p = prob[b];
+  const float den = fmaxf((1.f - p) * p, 1e-12f);
+  dprob[b] = weight * gout[0] * (p - target) / den / (float)B;
+}
+
+// ---- class-aware loss ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cal_loss_kernel(const float* __restrict__ S, const int* __restrict__ labels,
+                                                       int B, int D, float* __restrict__ loss, int accumulate,
+                                                       float* __restrict__ dS) {
+  __shared__ float sh[3][256];
+  float all = 0.f, pair = 0.f, cnt = 0.f;
+  for (int e = threadIdx.x; e < B * B; e += 256) {
+    const int i = e / B, j = e - i * B;
+    const float v = S[e];
+    all += v;
+    if (i != j && labels[i] == labels[j]) { pair += v; cnt += 1.f; }
+  }
+  sh[0][threadIdx.x] = all; sh[1][threadIdx.x] = pair; sh[2][threadIdx.x] = cnt;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  const float n = sh[2][0];
+  const float diff = n > 0.f ? sh[0][0] / (float)(B * B) - sh[1][0] / n : 0.f;
+  const bool active = n > 0.f && diff > 0.f;
+  if (threadIdx.x == 0) {
+    const float v = active ? diff / (float)D : 0.f;
+    loss[0] = accumulate ? loss[0] + v : v;
+  }
+  if (dS) {
+    // d loss / d S, symmetrised so that dX = dS_sym * X
+    for (int e = threadIdx.x; e < B * B; e += 256) {
+      const int i = e / B, j = e - i * B;
+      float g = 0.f;
+      if (active) {
+        const float m = (i != j && labels[i] == labels[j]) ? 1.f : 0.f;
+        g = 2.f * (1.f / (float)(B * B) - m / n) / (float)D;
+      }
+      dS[e] = g;
+    }
+  }
+}
+
+// ---- optimiser ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n4,
+                                                   long long n, float lr, float b1, float b2, float eps, int step,
+                                                   const int* __restrict__ step_dev, float gscale) {
+  __shared__ float bc[2];
+  if (threadIdx.x == 0) {
+    const int t = step_dev ? step_dev[0] : step;
+    bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  }
+  __syncthreads();
+  const float step_size = lr / bc[0];
+  const float bc2s = bc[1];
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4;
+       e += (long long)gridDim.x * blockDim.x) {
+    if (e * 4 + 3 < n) {
+      f32x4 pv = ld4(p + e * 4), gv = ld4(g + e * 4), mv = ld4(m + e * 4), vv = ld4(v + e * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float gg = gv[j] * gscale;
+        mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+        pv[j] -= step_size * mv[j] / (sqrtf(vv[j]) / bc2s + eps);
+      }
+      st4(p + e * 4, pv); st4(m + e * 4, mv); st4(v + e * 4, vv);
+    } else {
+      for (long long k = e * 4; k < n; ++k) {
+        const float gg = g[k] * gscale;
+        const float mm = b1 * m[k] + (1.f - b1) * gg;
+        const float vv = b2 * v[k] + (1.f - b2) * gg * gg;
+        m[k] = mm; v[k] = vv;
+        p[k] -= step_size * mm / (sqrtf(vv) / bc2s + eps);
+      }
+    }
+  }
+}
+__global__ void ema_kernel(float* __restrict__ avg, const float* __restrict__ p, long long n, float decay) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x)
+    avg[e] = decay * avg[e] + (1.f - decay) * p[e];
+}
+__global__ void axpby_kernel(float* __restrict__ y, const float* __restrict__ x, long long n, float a, float b) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x)
+    y[e] = a * x[e] + (b != 0.f ? b * y[e] : 0.f);
+}
+__global__ void scale_dev_kernel(float* __restrict__ y, const float* __restrict__ x, long long n,
+                                 const float* __restrict__ a) {
+  const float av = a[0];
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (long long)gridDim.x * blockDim.x)
+    y[e] = x[e] * av;
+}
+__global__ void increment_kernel(int* c) { c[0] += 1; }
+
+inline int grid_for(long long total, int block = 256, int cap = 2048 * 4) {
+  long long g = (total + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int s2i_colstats(const float* y, long long M, int C, int ldy, float* part, int nparts, void* stream) {
+  S2I_REQUIRE(y && part && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && nparts > 0, "colstats: bad args");
+  RedGeom g = red_geom(C);
+  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts, g.gy), dim3(256), 0, ST, y, ldy, (const float*)nullptr, 0,
+                     M, C, (const float*)nullptr, 0, part, nparts, g.cpb);
+  S2I_LAUNCH_CHECK("colstats");
+  return 0;
+}
+
+static int launch_finalize(int mode, const float* part, int nparts, int C, long long count, const float* gamma,
+                           const float* beta, float* rmean, float* rvar, float momentum, float eps, float* out,
+                           float* dgamma, float* dbeta, int accumulate, void* stream) {
+  S2I_REQUIRE(part && out && nparts > 0 && C > 0 && C % 4 == 0 && count > 0, "bn finalize: bad args");
+  const int Q = C / 4;
+  int qpb = 1;
+  while (qpb < Q && qpb < 32) qpb <<= 1;
+  const int grid = (Q + qpb - 1) / qpb;
+  const size_t shbytes = 2 * 1024 * 4 * sizeof(double);
+  if (mode == 0)
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb);
+  else
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb);
+  S2I_LAUNCH_CHECK("bn_finalize");
+  return 0;
+}
+
+extern "C" int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum,
+                               float eps, float* out4, void* stream) {
+  S2I_REQUIRE(gamma && beta, "bn_finalize: null affine parameters");
+  S2I_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+  return launch_finalize(0, part, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, out4,
+                         nullptr, nullptr, 0, stream);
+}
+
+extern "C" int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* out4, void* stream) {
+  S2I_REQUIRE(C > 0 && gamma && beta && running_mean && running_var && out4, "bn_eval_coeffs: bad args");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, C, gamma, beta, running_mean,
+                     running_var, eps, out4);
+  S2I_LAUNCH_CHECK("bn_eval_coeffs");
+  return 0;
+}
+
+extern "C" int s2i_bn_act_forward(const float* y, long long M, int C, const float* coef4, int act,
+                                  const float* residual, float* out, void* stream) {
+  S2I_REQUIRE(y && coef4 && out && M > 0 && C > 0, "bn_act_forward: bad args");
+  S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_forward: C=%d not aligned for act %d", C, act);
+  S2I_REQUIRE(!(residual && act == S2I_ACT_GLU), "bn_act_forward: residual with GLU unsupported");
+  const long long total = M * ((act == S2I_ACT_GLU ? C / 2 : C) / 4);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out);
+  S2I_LAUNCH_CHECK("bn_act_forward");
+  return 0;
+}
+
+extern "C" int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int C,
+                                     const float* coef4, int act, float* part, int nparts, void* stream) {
+  S2I_REQUIRE(y && dout && coef4 && part && M > 0 && nparts > 0, "bn_act_bwd_reduce: bad args");
+  S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_reduce: C alignment");
+  S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_reduce: lddout alignment");
+  RedGeom g = red_geom(C);
+  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
+                     act, part, nparts, g.cpb);
+  S2I_LAUNCH_CHECK("bn_act_bwd_reduce");
+  return 0;
+}
+
+extern "C" int s2i_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+                                   float* dbeta, int accumulate, float* red2, void* stream) {
+  return launch_finalize(1, part, nparts, C, count, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, red2, dgamma,
+                         dbeta, accumulate, stream);
+}
+
+extern "C" int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int C,
+                                    const float* coef4, const float* red2, int act, float* dy, void* stream) {
+  S2I_REQUIRE(y && dout && coef4 && red2 && dy && M > 0, "bn_act_bwd_apply: bad args");
+  S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_apply: C alignment");
+  S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_apply: lddout alignment");
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
+                     coef4, red2, act, dy);
+  S2I_LAUNCH_CHECK("bn_act_bwd_apply");
+  return 0;
+}
+
+extern "C" int s2i_act_backward(const float* out, const float* dout, int lddout, long long M, int C, int act,
+                                float* dy, void* stream) {
+  S2I_REQUIRE(out && dout && dy && M > 0 && C > 0 && C % 4 == 0 && lddout % 4 == 0, "act_backward: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
+  S2I_LAUNCH_CHECK("act_backward");
+  return 0;
+}
+
+extern "C" int s2i_glu_forward(const float* x, long long M, int C, float* out, void* stream) {
+  S2I_REQUIRE(x && out && M > 0 && C > 0 && C % 2 == 0, "glu_forward: bad args");
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(M * (C / 2))), dim3(256), 0, ST, x, M, C, out);
+  S2I_LAUNCH_CHECK("glu_forward");
+  return 0;
+}
+extern "C" int s2i_glu_backward(const float* x, const float* dout, long long M, int C, float* dx, void* stream) {
+  S2I_REQUIRE(x && dout && dx && M > 0 && C > 0 && C % 2 == 0, "glu_backward: bad args");
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(M * (C / 2))), dim3(256), 0, ST, x, dout, M, C, dx);
+  S2I_LAUNCH_CHECK("glu_backward");
+  return 0;
+}
+
+extern "C" int s2i_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+  S2I_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad args");
+  if (C == 3 && Cp == 4) {
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, ST, src, dst, B,
+                       H * W);
+  } else {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * H * W * Cp)), dim3(256), 0, ST, src, dst, B,
+                       C, H * W, Cp);
+  }
+  S2I_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+extern "C" int s2i_nhwc_to_nchw(const float* src, int lds, float* dst, int B, int C, int H, int W, void* stream) {
+  S2I_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && lds >= C, "nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, ST, src, lds, dst,
+                     B, C, H * W);
+  S2I_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+
+static int spatial_segments(int HW) {
+  int S = HW / 64;
+  if (S > 64) S = 64;
+  if (S < 1) S = 1;
+  return S;
+}
+extern "C" size_t s2i_spatial_sum_workspace_bytes(int B, int HW, int C) {
+  return (size_t)B * spatial_segments(HW) * C * sizeof(float);
+}
+extern "C" int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, float* dst, void* ws, size_t ws_bytes,
+                               void* stream) {
+  S2I_REQUIRE(src && dst && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C,
+              "spatial_sum: bad args");
+  const int S = spatial_segments(HW);
+  S2I_REQUIRE(ws && ws_bytes >= (size_t)B * S * C * sizeof(float), "spatial_sum: workspace too small");
+  RedGeom g = red_geom(C);
+  hipLaunchKernelGGL(spatial_sum_stage1, dim3(B, S, g.gy), dim3(256), 0, ST, src, ld, HW, C, S, (float*)ws, g.cpb);
+  S2I_LAUNCH_CHECK("spatial_sum_stage1");
+  hipLaunchKernelGGL(spatial_sum_stage2, dim3((B * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, S, C, dst);
+  S2I_LAUNCH_CHECK("spatial_sum_stage2");
+  return 0;
+}
+
+extern "C" int s2i_reparam_forward(const float* h, const float* eps, int B, int E, float* c, void* stream) {
+  S2I_REQUIRE(h && eps && c && B > 0 && E > 0, "reparam_forward: bad args");
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3((B * E + 255) / 256), dim3(256), 0, ST, h, eps, B, E, c);
+  S2I_LAUNCH_CHECK("reparam_forward");
+  return 0;
+}
+extern "C" int s2i_reparam_backward(const float* h, const float* eps, const float* dc, const float* dmu,
+                                    const float* dlogvar, int B, int E, float* dh, void* stream) {
+  S2I_REQUIRE(h && eps && dh && B > 0 && E > 0, "reparam_backward: bad args");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3((B * E + 255) / 256), dim3(256), 0, ST, h, eps, dc, dmu, dlogvar, B, E,
+                     dh);
+  S2I_LAUNCH_CHECK("reparam_backward");
+  return 0;
+}
+extern "C" int s2i_kl_forward(const float* mu, int ldmu, const float* logvar, int ldlv, int B, int E, float* kl,
+                              void* stream) {
+  S2I_REQUIRE(mu && logvar && kl && B > 0 && E > 0, "kl_forward: bad args");
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, ST, mu, ldmu, logvar, ldlv, B, E, kl);
+  S2I_LAUNCH_CHECK("kl_forward");
+  return 0;
+}
+extern "C" int s2i_kl_backward(const float* mu, int ldmu, const float* logvar, int ldlv, int B, int E,
+                               const float* gout, float* dmu, float* dlogvar, void* stream) {
+  S2I_REQUIRE(mu && logvar && gout && dmu && dlogvar && B > 0 && E > 0, "kl_backward: bad args");
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3((B * E + 255) / 256), dim3(256), 0, ST, mu, ldmu, logvar, ldlv, B, E, gout,
+                     dmu, dlogvar);
+  S2I_LAUNCH_CHECK("kl_backward");
+  return 0;
+}
+
+extern "C" int s2i_logit_forward(const float* x, const float* w, const float* bias, int B, int C, float* prob,
+                                 void* stream) {
+  S2I_REQUIRE(x && w && prob && B > 0 && C > 0, "logit_forward: bad args");
+  hipLaunchKernelGGL(logit_fwd_kernel, dim3(B), dim3(256), 0, ST, x, w, bias, C, prob);
+  S2I_LAUNCH_CHECK("logit_forward");
+  return 0;
+}
+extern "C" int s2i_logit_backward(const float* x, const float* w, const float* prob, const float* dprob, int B, int C,
+                                  float* dx, int acc_dx, float* dw, float* dbias, int acc_dw, void* stream) {
+  S2I_REQUIRE(x && w && prob && dprob && B > 0 && C > 0, "logit_backward: bad args");
+  hipLaunchKernelGGL(logit_bwd_kernel, dim3((16 * C + 255) / 256), dim3(256), 0, ST, x, w, prob, dprob, B, C, dx,
+                     acc_dx, dw, dbias, acc_dw);
+  S2I_LAUNCH_CHECK("logit_backward");
+  return 0;
+}
+extern "C" int s2i_bce_forward(const float* prob, float target, int B, float weight, float* loss, int accumulate,
+                               void* stream) {
+  S2I_REQUIRE(prob && loss && B > 0, "bce_forward: bad args");
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(256), 0, ST, prob, target, B, weight, loss, accumulate);
+  S2I_LAUNCH_CHECK("bce_forward");
+  return 0;
+}
+extern "C" int s2i_bce_backward(const float* prob, float target, int B, float weight, const float* gout,
+                                float* dprob, void* stream) {
+  S2I_REQUIRE(prob && gout && dprob && B > 0, "bce_backward: bad args");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, ST, prob, target, B, weight, gout, dprob);
+  S2I_LAUNCH_CHECK("bce_backward");
+  return 0;
+}
+
+extern "C" int s2i_cal_loss(const float* scores, const int* labels, int B, int D, float* loss, int accumulate,
+                            float* dscores_sym, void* stream) {
+  S2I_REQUIRE(scores && labels && loss && B > 0 && D > 0, "cal_loss: bad args");
+  hipLaunchKernelGGL(cal_loss_kernel, dim3(1), dim3(256), 0, ST, scores, labels, B, D, loss, accumulate, dscores_sym);
+  S2I_LAUNCH_CHECK("cal_loss");
+  return 0;
+}
+
+extern "C" int s2i_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1,
+                             float beta2, float eps, int step, const int* step_dev, float gscale, void* stream) {
+  S2I_REQUIRE(p && g && m && v && n > 0, "adam_step: bad args");
+  S2I_REQUIRE(step_dev || step >= 1, "adam_step: step must be >= 1");
+  const long long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4)), dim3(256), 0, ST, p, g, m, v, n4, n, lr, beta1, beta2, eps,
+                     step, step_dev, gscale);
+  S2I_LAUNCH_CHECK("adam_step");
+  return 0;
+}
+extern "C" int s2i_increment(int* counter, void* stream) {
+  S2I_REQUIRE(counter, "increment: null");
+  hipLaunchKernelGGL(increment_kernel, dim3(1), dim3(1), 0, ST, counter);
+  S2I_LAUNCH_CHECK("increment");
+  return 0;
+}
+extern "C" int s2i_ema_update(float* avg, const float* p, long long n, float decay, void* stream) {
+  S2I_REQUIRE(avg && p && n > 0, "ema_update: bad args");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n)), dim3(256), 0, ST, avg, p, n, decay);
+  S2I_LAUNCH_CHECK("ema_update");
+  return 0;
+}
+extern "C" int s2i_scale_dev(float* y, const float* x, long long n, const float* a_dev, void* stream) {
+  S2I_REQUIRE(y && x && a_dev && n > 0, "scale_dev: bad args");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, ST, y, x, n, a_dev);
+  S2I_LAUNCH_CHECK("scale_dev");
+  return 0;
+}
+extern "C" int s2i_axpby(float* y, const float* x, long long n, float a, float b, void* stream) {
+  S2I_REQUIRE(y && x && n > 0, "axpby: bad args");
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, ST, y, x, n, a, b);
+  S2I_LAUNCH_CHECK("axpby");
+  return 0;
+}

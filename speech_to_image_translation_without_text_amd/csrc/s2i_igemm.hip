@@ -1,0 +1,707 @@
+// Implicit-GEMM convolution kernels for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32, bit-exact f32 fma chain).
+//
+// One gather formulation covers every convolution on the StackGAN-v2 path
+// (reference StackGAN_v2/model.py:125-140, 144-169, 287-298, 358-398):
+//   K1    : 1x1 / nn.Linear
+//   K3S1  : conv3x3 pad 1 (and, with flipped taps + transposed weights, its input gradient)
+//   K4S2  : Conv2d(k4,s2,p1) of the D towers; also the input gradient of an upBlock
+//   TCONV : 4-phase transposed k4 s2 p1 conv = nearest-x2 upsample + conv3x3 collapsed to 2x2 taps
+//           per output parity (2.25x fewer MACs than the literal upsample+conv); also the input
+//           gradient of Conv2d(k4,s2,p1)
+// Activations are NHWC so the K (channel) direction of the gather is contiguous in HBM; a per-image
+// vector (c_code) can be concatenated in front of the stored channels without materialising the
+// torch.cat of model.py:277/434.
+//
+// Tile: 256 threads = 4 waves; block tile BM x BN x 32; each wave owns TM x TN MFMA tiles of 32x32.
+// LDS holds A as [k][m] and B as [k][n] so a fragment read is 32 consecutive floats per half-wave
+// (ds_read_b32, conflict-free).  Global->LDS staging goes through registers with the next chunk's
+// loads in flight during the MFMA loop.
+#include "s2i_common.h"
+
+namespace {
+
+struct IgemmP {
+  const float* __restrict__ x;
+  const float* __restrict__ cvec;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  float* __restrict__ part;
+  float* __restrict__ slab;
+  int B, H, W, Cx, Cc, Ca;
+  int Ho, Wo, lgWo, lgHoWo;
+  int M, N, K, T;
+  int kind, flip, act, stats, splitk, cps, nchunks;
+  int ldw, wR, ldy, nparts;
+  long long Mrows;
+};
+
+__device__ __forceinline__ void geom(int kind, int& s, int& pad, int& kw) {
+  if (kind == S2I_CONV_K3S1) { s = 1; pad = 1; kw = 3; }
+  else if (kind == S2I_CONV_K4S2) { s = 2; pad = 1; kw = 4; }
+  else { s = 1; pad = 0; kw = 1; }
+}
+
+__device__ __forceinline__ void tap_delta(int kind, int kw, int t, int py, int px, int& dy, int& dx) {
+  if (kind == S2I_TCONV_K4S2) {
+    const int a = t >> 1, b = t & 1;
+    dy = a ? (py ? 1 : -1) : 0;
+    dx = b ? (px ? 1 : -1) : 0;
+  } else {
+    dy = t / kw;
+    dx = t - dy * kw;
+  }
+}
+
+// which tap of the packed weight tensor the gather tap t multiplies
+__device__ __forceinline__ int tap_weight(int kind, int flip, int T, int t, int py, int px) {
+  if (kind == S2I_TCONV_K4S2) {
+    const int a = t >> 1, b = t & 1;
+    const int k4y = py ? (a ? 0 : 2) : (a ? 3 : 1);
+    const int k4x = px ? (b ? 0 : 2) : (b ? 3 : 1);
+    return k4y * 4 + k4x;
+  }
+  return flip ? (T - 1 - t) : t;
+}
+
+template <int TM, int TN, int LDA, int LDB>
+__device__ __forceinline__ void mma_chunk(const float* As, const float* Bs, int arow0, int bcol0,
+                                          int lane, f32x16 (&acc)[TM][TN]) {
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int k = 2 * kk + lh;
+    float a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + arow0 + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + bcol0 + j * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT>
+__global__ __launch_bounds__(256) void igemm_fwd_kernel(IgemmP p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int LDA = BM + 1;
+  constexpr int LDB = WT ? BN + 1 : BN;
+  constexpr int ASLOTS = BM / 32;
+  constexpr int BSLOTS = BN / 32;
+  constexpr int BROWS_PER_PASS = 1024 / BN;
+  __shared__ __attribute__((aligned(16))) float smem[32 * LDA + 32 * LDB + 4];
+  float* As = smem + (WT ? 0 : 32 * LDB);  // keep the b128-written array 16-byte aligned
+  float* Bs = smem + (WT ? 32 * LDA : 0);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int phase = 0, split = blockIdx.z;
+  if (p.kind == S2I_TCONV_K4S2) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  const int py = phase >> 1, px = phase & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kq = tid & 7, mrow = tid >> 3;
+  int s, pad, kw;
+  geom(p.kind, s, pad, kw);
+
+  long long abase[ASLOTS];
+  unsigned amask[ASLOTS];
+  int acoff[ASLOTS];
+#pragma unroll
+  for (int i = 0; i < ASLOTS; ++i) {
+    const int m = m0 + mrow + 32 * i;
+    unsigned mask = 0;
+    long long base = 0;
+    int coff = 0;
+    if (m < p.M) {
+      const int b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+      const int by = oy * s - pad, bx = ox * s - pad;
+      for (int t = 0; t < p.T; ++t) {
+        int dy, dx;
+        tap_delta(p.kind, kw, t, py, px, dy, dx);
+        const int iy = by + dy, ix = bx + dx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
+      }
+      base = (((long long)b * p.H + by) * p.W + bx) * p.Cx;
+      coff = b * p.Cc;
+    }
+    abase[i] = base;
+    amask[i] = mask;
+    acoff[i] = coff;
+  }
+  // direct-mode B mapping
+  const int bcol4 = tid % (BN / 4), brow = tid / (BN / 4);
+
+  f32x4 ra[ASLOTS], rb[BSLOTS];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int kc) {
+    const int k = kc * 32 + kq * 4;
+    int t = 0, c = 0, tw = 0;
+    long long toff = 0;
+    const bool kvalid = k < p.K;
+    if (kvalid) {
+      t = k / p.Ca;
+      c = k - t * p.Ca;
+      int dy, dx;
+      tap_delta(p.kind, kw, t, py, px, dy, dx);
+      toff = ((long long)dy * p.W + dx) * p.Cx + (c - p.Cc);
+      tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+    }
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+      f32x4 v = zero4;
+      if (kvalid && ((amask[i] >> t) & 1u)) {
+        if (c < p.Cc) v = *reinterpret_cast<const f32x4*>(p.cvec + acoff[i] + c);
+        else v = *reinterpret_cast<const f32x4*>(p.x + abase[i] + toff);
+      }
+      ra[i] = v;
+    }
+    if (WT) {
+#pragma unroll
+      for (int j = 0; j < BSLOTS; ++j) {
+        const int n = n0 + mrow + 32 * j;
+        f32x4 v = zero4;
+        if (kvalid && n < p.N)
+          v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tw * p.wR + n) * p.ldw + c);
+        rb[j] = v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < BSLOTS; ++q) {
+        const int kb = kc * 32 + brow + q * BROWS_PER_PASS;
+        const int n = n0 + bcol4 * 4;
+        f32x4 v = zero4;
+        if (kb < p.K && n < p.ldw) {
+          const int tb = kb / p.Ca;
+          const int cb = kb - tb * p.Ca;
+          const int twb = tap_weight(p.kind, p.flip, p.T, tb, py, px);
+          v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)twb * p.wR + cb) * p.ldw + n);
+        }
+        rb[q] = v;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int kc = c_begin; kc < c_end; ++kc) {
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * LDA + mrow + 32 * i] = ra[i][j];
+    if (WT) {
+#pragma unroll
+      for (int i = 0; i < BSLOTS; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDB + mrow + 32 * i] = rb[i][j];
+    } else {
+#pragma unroll
+      for (int q = 0; q < BSLOTS; ++q)
+        *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS_PER_PASS) * LDB + bcol4 * 4) = rb[q];
+    }
+    __syncthreads();
+    if (kc + 1 < c_end) fetch(kc + 1);
+    mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const int l31 = lane & 31, lh = lane >> 5;
+  const bool tconv = p.kind == S2I_TCONV_K4S2;
+  const bool raw = p.splitk > 1;
+  float* outp = raw ? p.slab + (size_t)split * p.Mrows * p.N : p.y;
+  const int ldo = raw ? p.N : p.ldy;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + ml;
+      if (m >= p.M) continue;
+      long long row = m;
+      if (tconv) {
+        const int b = m >> p.lgHoWo;
+        const int rr = m & ((1 << p.lgHoWo) - 1);
+        const int oy = rr >> p.lgWo, ox = rr & (p.Wo - 1);
+        row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) {
+          float v = acc[i][j][r];
+          if (!raw) {
+            if (p.bias) v += p.bias[n];
+            if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+            else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+          }
+          outp[row * ldo + n] = v;
+        }
+      }
+    }
+  }
+
+  if (p.stats && !raw) {
+    // column sums over this block's rows; rows >= M gathered zeros and contribute nothing
+    float* red = smem;  // [2][WAVES_M][BN]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          sv += v;
+          sq += v * v;
+        }
+      sv += __shfl_xor(sv, 32);
+      sq += __shfl_xor(sq, 32);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + j * 32 + l31;
+        red[(0 * WAVES_M + wm) * BN + col] = sv;
+        red[(1 * WAVES_M + wm) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.N) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES_M; ++q) {
+          sv += red[(0 * WAVES_M + q) * BN + tid];
+          sq += red[(1 * WAVES_M + q) * BN + tid];
+        }
+        const int gm = phase * gridDim.x + blockIdx.x;
+        p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
+        p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long long rows, int N,
+                                     const float* __restrict__ bias, int act, float* __restrict__ y,
+                                     int ldy) {
+  const long long total = rows * N;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long row = e / N;
+    const int n = (int)(e - row * N);
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += slab[(size_t)s * total + e];
+    if (bias) v += bias[n];
+    if (act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+    else if (act == S2I_ACT_TANH) v = tanhf(v);
+    y[row * ldy + n] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: slab[split][krow][n] = sum_{pixels in split} A(pixel, krow) * g[pixel][n]
+struct WgradP {
+  const float* __restrict__ a;
+  const float* __restrict__ cvec;
+  const float* __restrict__ g;
+  float* __restrict__ slab;
+  int B, H, W, Ca, Cc, Cin;
+  int Ho, Wo, lgWo, lgHoWo;
+  int M, N, ldg, K, T, kind;
+  int cps, nchunks;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradP p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int LDA = BM, LDB = BN;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int AROWS = 1024 / BM, BROWS = 1024 / BN;
+  __shared__ __attribute__((aligned(16))) float smem[32 * LDA + 32 * LDB];
+  float* As = smem;
+  float* Bs = smem + 32 * LDA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  int s, pad, kw;
+  geom(p.kind, s, pad, kw);
+
+  const int acol4 = tid % (BM / 4), arow = tid / (BM / 4);
+  const int bcol4 = tid % (BN / 4), brow = tid / (BN / 4);
+  // this thread's 4 gathered columns: fixed (tap, channel) for the whole pixel loop
+  const int kcol = k0 + acol4 * 4;
+  const bool kvalid = kcol < p.K;
+  int c = 0, dy = 0, dx = 0;
+  if (kvalid) {
+    const int t = kcol / p.Cin;
+    c = kcol - t * p.Cin;
+    dy = t / kw;
+    dx = t - dy * kw;
+  }
+  const bool from_vec = c < p.Cc;
+  const int nb = n0 + bcol4 * 4;
+  const bool nvalid = nb < p.N;
+
+  f32x4 ra[APASS], rb[BPASS];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      const int m = pc * 32 + arow + q * AROWS;
+      f32x4 v = zero4;
+      if (kvalid && m < p.M) {
+        const int b = m >> p.lgHoWo;
+        const int r = m & ((1 << p.lgHoWo) - 1);
+        const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+        const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+          if (from_vec) v = *reinterpret_cast<const f32x4*>(p.cvec + b * p.Cc + c);
+          else
+            v = *reinterpret_cast<const f32x4*>(p.a + (((long long)b * p.H + iy) * p.W + ix) * p.Ca +
+                                                (c - p.Cc));
+        }
+      }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int m = pc * 32 + brow + q * BROWS;
+      f32x4 v = zero4;
+      if (nvalid && m < p.M) v = *reinterpret_cast<const f32x4*>(p.g + (long long)m * p.ldg + nb);
+      rb[q] = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int pc = c_begin; pc < c_end; ++pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q)
+      *reinterpret_cast<f32x4*>(As + (arow + q * AROWS) * LDA + acol4 * 4) = ra[q];
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q)
+      *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS) * LDB + bcol4 * 4) = rb[q];
+    __syncthreads();
+    if (pc + 1 < c_end) fetch(pc + 1);
+    mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+    __syncthreads();
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* outp = p.slab + (size_t)split * p.K * p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (krow >= p.K) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) outp[(size_t)krow * p.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// Reduce the split slabs and scatter into the reference's OIHW gradient tensor.
+// fold: the 3x3 parameter tap (ky,kx) collects the effective 4x4 taps it was summed into.
+__global__ void wgrad_finish_kernel(const float* __restrict__ slab, int S, int K, int N, int Cg, int O,
+                                    int I, int KH, int KW, int swap, int fold, int accumulate,
+                                    float* __restrict__ grad) {
+  const long long total = (long long)O * I * KH * KW;
+  const size_t sstride = (size_t)K * N;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int kx = (int)(e % KW);
+    const int ky = (int)((e / KW) % KH);
+    const int i = (int)((e / ((long long)KW * KH)) % I);
+    const int o = (int)(e / ((long long)KW * KH * I));
+    float v = 0.f;
+    const int ny = fold ? 2 : 1, nx = fold ? 2 : 1;
+    for (int ay = 0; ay < ny; ++ay)
+      for (int ax = 0; ax < nx; ++ax) {
+        int tap;
+        if (fold) {
+          const int k4y = (2 - ky) + ay, k4x = (2 - kx) + ax;  // ky=0:{2,3} ky=1:{1,2} ky=2:{0,1}
+          tap = k4y * 4 + k4x;
+        } else {
+          tap = ky * KW + kx;
+        }
+        const size_t off = swap ? ((size_t)tap * Cg + o) * N + i : ((size_t)tap * Cg + i) * N + o;
+        for (int s = 0; s < S; ++s) v += slab[s * sstride + off];
+      }
+    grad[e] = accumulate ? grad[e] + v : v;
+  }
+}
+
+// OIHW -> packed P[t][i][op]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int O, int I,
+                                   int KH, int KW, int Ip, int Op, int T, int mode) {
+  const long long total = (long long)T * Ip * Op;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(e % Op);
+    const int i = (int)((e / Op) % Ip);
+    const int t = (int)(e / ((long long)Op * Ip));
+    float v = 0.f;
+    if (o < O && i < I) {
+      const float* wp = w + ((size_t)o * I + i) * KH * KW;
+      if (mode == S2I_PACK_UPFOLD) {
+        // effective tap k4 sums parameter taps: 0:{2} 1:{1,2} 2:{0,1} 3:{0}
+        const int k4y = t >> 2, k4x = t & 3;
+        const int ylo = k4y == 0 ? 2 : (k4y == 1 ? 1 : 0), yhi = k4y == 0 ? 2 : (k4y == 1 ? 2 : (k4y == 2 ? 1 : 0));
+        const int xlo = k4x == 0 ? 2 : (k4x == 1 ? 1 : 0), xhi = k4x == 0 ? 2 : (k4x == 1 ? 2 : (k4x == 2 ? 1 : 0));
+        for (int ky = ylo; ky <= yhi; ++ky)
+          for (int kx = xlo; kx <= xhi; ++kx) v += wp[ky * 3 + kx];
+      } else {
+        v = wp[t];
+      }
+    }
+    packed[e] = v;
+  }
+}
+
+// ---- host-side planning ------------------------------------------------------------------------
+struct FwdPlan {
+  int T, K, Ca, Ho, Wo, M, nphases, tile, gridM, gridN, nchunks, splitk, cps;
+  long long Mrows;
+};
+
+int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
+  S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "conv: non-positive extent");
+  S2I_REQUIRE(d->Cx >= 0 && d->Cc >= 0 && (d->Cx % 4) == 0 && (d->Cc % 4) == 0 && d->Cx + d->Cc > 0,
+              "conv: channel counts must be multiples of 4 (Cx=%d Cc=%d)", d->Cx, d->Cc);
+  S2I_REQUIRE(s2i_is_pow2(d->H) && s2i_is_pow2(d->W), "conv: spatial extents must be powers of two");
+  pl->Ca = d->Cx + d->Cc;
+  pl->nphases = 1;
+  switch (d->kind) {
+    case S2I_CONV_K1: pl->T = 1; pl->Ho = d->H; pl->Wo = d->W; break;
+    case S2I_CONV_K3S1: pl->T = 9; pl->Ho = d->H; pl->Wo = d->W; break;
+    case S2I_CONV_K4S2:
+      S2I_REQUIRE(d->H >= 2 && d->W >= 2, "conv k4s2: extent < 2");
+      pl->T = 16; pl->Ho = d->H / 2; pl->Wo = d->W / 2; break;
+    case S2I_TCONV_K4S2: pl->T = 4; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
+    default: S2I_FAIL("conv: unknown kind %d", d->kind);
+  }
+  const long long M = (long long)d->B * pl->Ho * pl->Wo;
+  S2I_REQUIRE(M * 4 < (1ll << 31), "conv: too many rows");
+  pl->M = (int)M;
+  pl->Mrows = M * pl->nphases;
+  pl->K = pl->T * pl->Ca;
+  if (d->wmode == 0) {
+    S2I_REQUIRE(d->wR == pl->Ca, "conv: wR (%d) must equal gathered channels (%d)", d->wR, pl->Ca);
+    S2I_REQUIRE(d->ldw >= d->N && d->ldw % 4 == 0, "conv: ldw %d too small for N %d", d->ldw, d->N);
+  } else {
+    S2I_REQUIRE(d->wR >= d->N, "conv(T): wR (%d) < N (%d)", d->wR, d->N);
+    S2I_REQUIRE(d->ldw >= pl->Ca, "conv(T): ldw (%d) < gathered channels (%d)", d->ldw, pl->Ca);
+  }
+  S2I_REQUIRE(d->ldy >= d->N, "conv: ldy < N");
+  S2I_REQUIRE(!(d->stats && (d->act != S2I_ACT_NONE)), "conv: stats epilogue needs act NONE");
+  pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
+  const int BN = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
+  pl->gridM = s2i_cdiv(M, 128);
+  pl->gridN = s2i_cdiv(d->N, BN);
+  pl->nchunks = s2i_cdiv(pl->K, 32);
+  const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
+  int splitk = 1;
+  if (blocks < 256 && pl->nchunks >= 16) {
+    splitk = (int)((768 + blocks - 1) / blocks);
+    if (splitk > pl->nchunks / 8) splitk = pl->nchunks / 8;
+    if (splitk > 64) splitk = 64;
+    if (splitk < 1) splitk = 1;
+  }
+  pl->cps = s2i_cdiv(pl->nchunks, splitk);
+  pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  return 0;
+}
+
+struct WgPlan {
+  int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps;
+};
+
+int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
+  S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "wgrad: non-positive extent");
+  S2I_REQUIRE((d->Ca % 4) == 0 && (d->Cc % 4) == 0 && (d->N % 4) == 0 && d->Ca + d->Cc > 0,
+              "wgrad: channel counts must be multiples of 4 (Ca=%d Cc=%d N=%d)", d->Ca, d->Cc, d->N);
+  S2I_REQUIRE(s2i_is_pow2(d->H) && s2i_is_pow2(d->W), "wgrad: spatial extents must be powers of two");
+  pl->Cin = d->Ca + d->Cc;
+  switch (d->kind) {
+    case S2I_CONV_K1: pl->T = 1; pl->Ho = d->H; pl->Wo = d->W; break;
+    case S2I_CONV_K3S1: pl->T = 9; pl->Ho = d->H; pl->Wo = d->W; break;
+    case S2I_CONV_K4S2: pl->T = 16; pl->Ho = d->H / 2; pl->Wo = d->W / 2; break;
+    default: S2I_FAIL("wgrad: unsupported gather kind %d", d->kind);
+  }
+  const long long M = (long long)d->B * pl->Ho * pl->Wo;
+  S2I_REQUIRE(M < (1ll << 30), "wgrad: too many rows");
+  pl->M = (int)M;
+  pl->K = pl->T * pl->Cin;
+  S2I_REQUIRE(d->ldg >= d->N, "wgrad: ldg < N");
+  // consistency of the OIHW target with the GEMM result
+  const int taps_param = d->KH * d->KW;
+  if (d->fold) S2I_REQUIRE(d->KH == 3 && d->KW == 3 && pl->T == 16, "wgrad: fold needs 3x3 param / 4x4 taps");
+  else S2I_REQUIRE(taps_param == pl->T, "wgrad: taps mismatch (%d vs %d)", taps_param, pl->T);
+  if (d->swap) S2I_REQUIRE(pl->Cin >= d->O && d->N == d->I, "wgrad(swap): shape mismatch");
+  else S2I_REQUIRE(pl->Cin >= d->I && d->N >= d->O, "wgrad: shape mismatch");
+  pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
+  const int BN = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
+  pl->gridK = s2i_cdiv(pl->K, 128);
+  pl->gridN = s2i_cdiv(d->N, BN);
+  pl->nchunks = s2i_cdiv(M, 32);
+  const long long tiles = (long long)pl->gridK * pl->gridN;
+  int splitk = (int)((1024 + tiles - 1) / tiles);
+  if (splitk > pl->nchunks / 4) splitk = pl->nchunks / 4;
+  if (splitk > 1024) splitk = 1024;
+  if (splitk < 1) splitk = 1;
+  pl->cps = s2i_cdiv(pl->nchunks, splitk);
+  pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_fwd(const IgemmP& p, dim3 grid, bool wt, hipStream_t st) {
+  if (wt) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace
+
+extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
+  FwdPlan pl;
+  if (plan_fwd(d, &pl)) return 0;
+  return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
+}
+
+// number of rows the stats pass writes; split-K layers take the column-stats kernel instead
+static int stat_parts_for(const FwdPlan& pl) {
+  if (pl.splitk > 1) {
+    int np = s2i_cdiv(pl.Mrows, 64);
+    return np > 256 ? 256 : np;
+  }
+  return pl.gridM * pl.nphases;
+}
+
+extern "C" int s2i_conv_stat_parts(const s2i_conv_desc* d) {
+  FwdPlan pl;
+  if (plan_fwd(d, &pl)) return -1;
+  return stat_parts_for(pl);
+}
+
+extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                                const float* bias, float* y, float* part, void* ws, size_t ws_bytes,
+                                void* stream) {
+  FwdPlan pl;
+  if (plan_fwd(d, &pl)) return 1;
+  S2I_REQUIRE(x != nullptr || d->Cx == 0, "conv: x is null");
+  S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "conv: cvec is null but Cc > 0");
+  S2I_REQUIRE(w && y, "conv: null weight/output");
+  S2I_REQUIRE(!d->stats || part, "conv: stats requested without a partial buffer");
+  const size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
+  S2I_REQUIRE(ws_bytes >= need && (need == 0 || ws), "conv: workspace too small (%zu < %zu)", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  IgemmP p;
+  p.x = x; p.cvec = cvec; p.w = w; p.bias = bias; p.y = y; p.part = part; p.slab = (float*)ws;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cx = d->Cx; p.Cc = d->Cc; p.Ca = pl.Ca;
+  p.Ho = pl.Ho; p.Wo = pl.Wo; p.lgWo = s2i_ilog2(pl.Wo); p.lgHoWo = s2i_ilog2(pl.Ho * pl.Wo);
+  p.M = pl.M; p.N = d->N; p.K = pl.K; p.T = pl.T;
+  p.kind = d->kind; p.flip = d->flip; p.act = d->act; p.stats = d->stats;
+  p.splitk = pl.splitk; p.cps = pl.cps; p.nchunks = pl.nchunks;
+  p.ldw = d->ldw; p.wR = d->wR; p.ldy = d->ldy; p.nparts = pl.gridM * pl.nphases;
+  p.Mrows = pl.Mrows;
+  dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
+  const bool wt = d->wmode != 0;
+  if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, st);
+  else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, st);
+  else launch_fwd<128, 32, 4, 1>(p, grid, wt, st);
+  S2I_LAUNCH_CHECK("igemm_fwd");
+  if (pl.splitk > 1) {
+    const long long total = pl.Mrows * d->N;
+    int blocks = s2i_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, pl.splitk,
+                       pl.Mrows, d->N, bias, d->act, y, d->ldy);
+    S2I_LAUNCH_CHECK("splitk_reduce");
+    if (d->stats) return s2i_colstats(y, pl.Mrows, d->N, d->ldy, part, stat_parts_for(pl), stream);
+  }
+  return 0;
+}
+
+extern "C" size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d) {
+  WgPlan pl;
+  if (plan_wgrad(d, &pl)) return 0;
+  return (size_t)pl.splitk * pl.K * d->N * sizeof(float);
+}
+
+extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
+                              float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  WgPlan pl;
+  if (plan_wgrad(d, &pl)) return 1;
+  S2I_REQUIRE((a || d->Ca == 0) && g && grad_oihw, "wgrad: null operand");
+  S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "wgrad: cvec is null but Cc > 0");
+  const size_t need = (size_t)pl.splitk * pl.K * d->N * sizeof(float);
+  S2I_REQUIRE(ws && ws_bytes >= need, "wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  WgradP p;
+  p.a = a; p.cvec = cvec; p.g = g; p.slab = (float*)ws;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Ca = d->Ca; p.Cc = d->Cc; p.Cin = pl.Cin;
+  p.Ho = pl.Ho; p.Wo = pl.Wo; p.lgWo = s2i_ilog2(pl.Wo); p.lgHoWo = s2i_ilog2(pl.Ho * pl.Wo);
+  p.M = pl.M; p.N = d->N; p.ldg = d->ldg; p.K = pl.K; p.T = pl.T; p.kind = d->kind;
+  p.cps = pl.cps; p.nchunks = pl.nchunks;
+  dim3 grid(pl.gridK, pl.gridN, pl.splitk);
+  if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
+  S2I_LAUNCH_CHECK("igemm_wgrad");
+  const long long total = (long long)d->O * d->I * d->KH * d->KW;
+  int blocks = s2i_cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, pl.splitk, pl.K,
+                     d->N, pl.Cin, d->O, d->I, d->KH, d->KW, d->swap, d->fold, d->accumulate, grad_oihw);
+  S2I_LAUNCH_CHECK("wgrad_finish");
+  return 0;
+}
+
+extern "C" int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int KH, int KW, int Ip,
+                                    int mode, void* stream) {
+  S2I_REQUIRE(w_oihw && packed, "pack: null pointer");
+  S2I_REQUIRE(O > 0 && I > 0 && KH > 0 && KW > 0 && Ip >= I, "pack: bad shape");
+  int T = KH * KW;
+  if (mode == S2I_PACK_UPFOLD) {
+    S2I_REQUIRE(KH == 3 && KW == 3, "pack: UPFOLD needs a 3x3 parameter");
+    T = 16;
+  } else {
+    S2I_REQUIRE(mode == S2I_PACK_PLAIN, "pack: unknown mode %d", mode);
+  }
+  const int Op = (O + 3) & ~3;
+  const long long total = (long long)T * Ip * Op;
+  int blocks = s2i_cdiv(total, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, O, I,
+                     KH, KW, Ip, Op, T, mode);
+  S2I_LAUNCH_CHECK("pack_weight");
+  return 0;
+}

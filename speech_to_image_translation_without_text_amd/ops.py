@@ -1,0 +1,578 @@
+"""Host-side operators of the MI355X StackGAN-v2 path: torch.autograd.Functions whose forward and
+backward are calls into the C-ABI kernels of include/s2i_hip.h (through _lib.py).
+
+Each Function stands in for a group of stock torch ops of the reference
+(StackGAN_v2/model.py:112-551, StackGAN_v2/trainer.py:54-58, 298-311, 394-409):
+
+  ConvBnAct   conv (1x1 / 3x3 / 4x4-s2 / nearest-x2+3x3) + BatchNorm(train) + GLU|LeakyReLU|none
+              (+ residual add): upBlock, Block3x3_relu, ResBlock halves, downBlock,
+              Block3x3_leakRelu, INIT_STAGE_G.fc
+  ConvAct     conv + bias + LeakyReLU|tanh|none: first D conv, GET_IMAGE_G, CA_NET.fc
+  Glu2d, Reparam, KLLoss        CA_NET encode / reparametrize, KL_loss
+  LogitHead, BCELoss, ClassAwareLoss   logits / uncond_logits + nn.BCELoss, class_aware_loss
+  ToNHWC / ToNCHW               layout changes at the module boundary
+
+Activations between these ops are NHWC; parameters stay in the reference's OIHW layout and are
+re-packed to the kernels' layout when their version counter changes.  There is no CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GLU, ACT_LRELU, ACT_NONE, ACT_TANH, CONV_K1, CONV_K3S1, CONV_K4S2,
+                   PACK_PLAIN, PACK_UPFOLD, TCONV_K4S2, ConvDesc, WgradDesc, check, ptr, stream)
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _lib_ready():
+    lib = _lib.load()
+    _lib.require_device()
+    return lib
+
+
+# ---- scratch ------------------------------------------------------------------------------------
+class _Workspace:
+    """One growable scratch buffer per device; kernels on a stream use it one after another."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        nbytes = max(int(nbytes), 16)
+        cur = self.buf.get(device)
+        if cur is None or cur.numel() * 4 < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise _lib.S2IError("workspace would grow during hipGraph capture; run a warm-up step first")
+            cur = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
+            self.buf[device] = cur
+        return cur
+
+
+_ws = _Workspace()
+
+
+def _roundup4(v):
+    return (v + 3) & ~3
+
+
+# ---- packed weights ------------------------------------------------------------------------------
+class _PackCache:
+    """OIHW parameter -> P[tap][Ip][Op]; refreshed when the parameter's version changes."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, w, mode):
+        key = (id(w), mode)
+        ent = self.entries.get(key)
+        ver = w._version
+        if (ent is not None and ent[3] is w and ent[1] == ver and ent[2] == w.data_ptr()
+                and ent[0].device == w.device):
+            return ent[0]
+        packed = ent[0] if ent is not None and ent[0].device == w.device else None
+        packed = pack_weight(w, mode, out=packed)
+        self.entries[key] = (packed, ver, w.data_ptr(), w)
+        return packed
+
+    def refresh(self, params):
+        """Re-pack after an in-place update that bypassed torch's version counter (fused Adam)."""
+        ids = {id(p) for p in params}
+        for (pid, mode), ent in list(self.entries.items()):
+            if pid in ids:
+                pack_weight(ent[3], mode, out=ent[0])
+
+    def clear(self):
+        self.entries.clear()
+
+
+_packs = _PackCache()
+
+
+def pack_weight(w, mode, out=None):
+    lib = _lib_ready()
+    w = w.detach()
+    if w.dim() == 2:
+        O, I, KH, KW = w.shape[0], w.shape[1], 1, 1
+    else:
+        O, I, KH, KW = w.shape
+    if not w.is_contiguous():
+        w = w.contiguous()
+    T = 16 if mode == PACK_UPFOLD else KH * KW
+    Ip, Op = _roundup4(I), _roundup4(O)
+    if out is None or out.numel() != T * Ip * Op:
+        out = torch.empty((T, Ip, Op), dtype=torch.float32, device=w.device)
+    check(lib.s2i_pack_conv_weight(ptr(w), ptr(out), O, I, KH, KW, Ip, mode, stream()), "s2i_pack_conv_weight")
+    return out
+
+
+def packed_weight(w, mode=PACK_PLAIN):
+    return _packs.get(w, mode)
+
+
+def refresh_packed(params):
+    _packs.refresh(list(params))
+
+
+def clear_caches():
+    _packs.clear()
+
+
+# ---- raw kernels ------------------------------------------------------------------------------------
+def _geom(kind, H, W):
+    if kind == CONV_K4S2:
+        return H // 2, W // 2
+    if kind == TCONV_K4S2:
+        return 2 * H, 2 * W
+    return H, W
+
+
+def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False):
+    """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts)."""
+    lib = _lib_ready()
+    B, H, W, Cx = x.shape
+    Cc = 0 if cvec is None else cvec.shape[1]
+    Ho, Wo = _geom(kind, H, W)
+    d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N)
+    y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
+    part, nparts = None, 0
+    if stats:
+        nparts = lib.s2i_conv_stat_parts(ctypes.byref(d))
+        if nparts <= 0:
+            check(1, "s2i_conv_stat_parts")
+        part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
+    wsb = lib.s2i_conv_workspace_bytes(ctypes.byref(d))
+    ws = _ws.get(wsb, x.device)
+    check(lib.s2i_conv_forward(ctypes.byref(d), ptr(x), ptr(cvec), ptr(packed), ptr(bias), ptr(y), ptr(part),
+                               ptr(ws), ws.numel() * 4, stream()), "s2i_conv_forward")
+    return y, part, nparts
+
+
+def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False):
+    """Weight gradient into an OIHW tensor of shape grad_shape.  a: gathered NHWC, g: plain NHWC."""
+    lib = _lib_ready()
+    B, H, W, Ca = a.shape
+    Cc = 0 if cvec is None else cvec.shape[1]
+    N = g.shape[-1]
+    if len(grad_shape) == 2:
+        O, I, KH, KW = grad_shape[0], grad_shape[1], 1, 1
+    else:
+        O, I, KH, KW = grad_shape
+    d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0)
+    if out is None:
+        out = torch.empty(grad_shape, dtype=torch.float32, device=a.device)
+    wsb = lib.s2i_wgrad_workspace_bytes(ctypes.byref(d))
+    if wsb == 0:
+        check(1, "s2i_wgrad_workspace_bytes")
+    ws = _ws.get(wsb, a.device)
+    check(lib.s2i_conv_wgrad(ctypes.byref(d), ptr(a), ptr(cvec), ptr(g), ptr(out), ptr(ws), ws.numel() * 4,
+                             stream()), "s2i_conv_wgrad")
+    return out
+
+
+def _rows_view(t):
+    """(tensor usable by the kernels, row stride) for a NHWC gradient that may be a channel slice."""
+    C = t.shape[-1]
+    if t.is_contiguous():
+        return t, C
+    st = t.stride()
+    if t.dim() >= 2 and st[-1] == 1 and st[-2] % 4 == 0 and t.data_ptr() % 16 == 0:
+        ld = st[-2]
+        ok = True
+        expect = ld
+        for dim in range(t.dim() - 2, -1, -1):
+            if t.shape[dim] != 1 and st[dim] != expect:
+                ok = False
+                break
+            expect *= t.shape[dim]
+        if ok:
+            return t, ld
+    return t.contiguous(), C
+
+
+def _num_parts(M):
+    return int(max(1, min(1024, M // 64)))
+
+
+# ---- conv + BatchNorm + activation ---------------------------------------------------------------------
+_KIND = {"k1": CONV_K1, "k3s1": CONV_K3S1, "k4s2": CONV_K4S2, "up": TCONV_K4S2}
+
+
+def _dgrad(kind_name, dy, w, packed, n_in):
+    """Input gradient of the conv `kind_name` given dy (NHWC) -> [B,H,W,n_in]."""
+    Op = packed.shape[2]
+    if dy.shape[-1] != Op:
+        raise _lib.S2IError("dgrad: dy has %d channels, packed weight %d" % (dy.shape[-1], Op))
+    if kind_name == "k3s1":
+        y, _, _ = conv_raw(CONV_K3S1, dy, None, packed, n_in, wmode=1, flip=1, wR=packed.shape[1], ldw=Op)
+    elif kind_name == "k4s2":
+        y, _, _ = conv_raw(TCONV_K4S2, dy, None, packed, n_in, wmode=1, wR=packed.shape[1], ldw=Op)
+    elif kind_name == "up":
+        y, _, _ = conv_raw(CONV_K4S2, dy, None, packed, n_in, wmode=1, wR=packed.shape[1], ldw=Op)
+    else:
+        y, _, _ = conv_raw(CONV_K1, dy, None, packed, n_in, wmode=1, wR=packed.shape[1], ldw=Op)
+    return y
+
+
+def _wgrad(kind_name, x, cvec, dy, w_shape):
+    if kind_name == "up":
+        return wgrad_raw(CONV_K4S2, dy, None, x, tuple(w_shape), swap=1, fold=1)
+    return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(w_shape))
+
+
+def _split_input_grad(dx_full, Cc):
+    """dx of the stored channels and the gradient of the broadcast vector."""
+    if Cc == 0:
+        return dx_full, None
+    lib = _lib_ready()
+    B, H, W, Ca = dx_full.shape
+    if H * W == 1:
+        dc = dx_full.reshape(B, Ca)[:, :Cc]
+    else:
+        dc = torch.empty((B, Cc), dtype=torch.float32, device=dx_full.device)
+        wsb = lib.s2i_spatial_sum_workspace_bytes(B, H * W, Cc)
+        ws = _ws.get(wsb, dx_full.device)
+        check(lib.s2i_spatial_sum(ptr(dx_full), Ca, B, H * W, Cc, ptr(dc), ptr(ws), ws.numel() * 4, stream()),
+              "s2i_spatial_sum")
+    return dx_full[..., Cc:], dc
+
+
+class ConvBnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training):
+        lib = _lib_ready()
+        x = x.contiguous()
+        if cvec is not None:
+            cvec = cvec.contiguous()
+        kind = _KIND[kind_name]
+        packed = packed_weight(weight, PACK_UPFOLD if kind_name == "up" else PACK_PLAIN)
+        Cout = weight.shape[0]
+        y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2], stats=training)
+        M = y.numel() // Cout
+        coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
+        rm, rv, nbt = bn_buffers
+        if training:
+            check(lib.s2i_bn_finalize(ptr(part), nparts, Cout, M, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+                                      BN_MOMENTUM, BN_EPS, ptr(coef), stream()), "s2i_bn_finalize")
+            if nbt is not None:
+                nbt.add_(1)
+        else:
+            check(lib.s2i_bn_eval_coeffs(Cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, ptr(coef), stream()),
+                  "s2i_bn_eval_coeffs")
+        Cact = Cout // 2 if act == ACT_GLU else Cout
+        out = torch.empty(y.shape[:-1] + (Cact,), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            residual = residual.contiguous()
+        check(lib.s2i_bn_act_forward(ptr(y), M, Cout, ptr(coef), act, ptr(residual), ptr(out), stream()),
+              "s2i_bn_act_forward")
+        ctx.save_for_backward(x, cvec, weight, gamma, y, coef)
+        ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib_ready()
+        x, cvec, weight, gamma, y, coef = ctx.saved_tensors
+        if not ctx.training:
+            raise _lib.S2IError("ConvBnAct.backward: eval-mode BatchNorm has no backward on this path")
+        Cout = weight.shape[0]
+        M = y.numel() // Cout
+        dout_k, ldd = _rows_view(dout)
+        nparts = _num_parts(M)
+        part = torch.empty((2, nparts, Cout), dtype=torch.float32, device=y.device)
+        check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ctx.act, ptr(part), nparts,
+                                        stream()), "s2i_bn_act_bwd_reduce")
+        dgamma = torch.empty_like(gamma)
+        dbeta = torch.empty_like(gamma)
+        red2 = torch.empty((2, Cout), dtype=torch.float32, device=y.device)
+        check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, Cout, M, ptr(dgamma), ptr(dbeta), 0, ptr(red2), stream()),
+              "s2i_bn_bwd_finalize")
+        dy = torch.empty_like(y)
+        check(lib.s2i_bn_act_bwd_apply(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ptr(red2), ctx.act, ptr(dy),
+                                       stream()), "s2i_bn_act_bwd_apply")
+        need_x, need_c, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dx = dc = dw = None
+        Cc = 0 if cvec is None else cvec.shape[1]
+        if need_x or (need_c and cvec is not None):
+            packed = packed_weight(weight, PACK_UPFOLD if ctx.kind_name == "up" else PACK_PLAIN)
+            dx_full = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1] + Cc)
+            dx, dc = _split_input_grad(dx_full, Cc)
+            if not need_x:
+                dx = None
+        if need_w:
+            dw = _wgrad(ctx.kind_name, x, cvec, dy, weight.shape)
+        dres = dout if ctx.has_res else None
+        return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None
+
+
+class ConvAct(torch.autograd.Function):
+    """conv (+bias) + LeakyReLU / tanh / none, no BatchNorm."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, kind_name, act, n_out):
+        x = x.contiguous()
+        kind = _KIND[kind_name]
+        packed = packed_weight(weight, PACK_PLAIN)
+        out, _, _ = conv_raw(kind, x, None, packed, n_out, wR=packed.shape[1], ldw=packed.shape[2], bias=bias, act=act)
+        ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
+        ctx.kind_name, ctx.act, ctx.has_bias, ctx.n_out = kind_name, act, bias is not None, n_out
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib_ready()
+        x, weight, out = ctx.saved_tensors
+        N = ctx.n_out
+        M = dout.numel() // N
+        dout_k, ldd = _rows_view(dout)
+        if ctx.act != ACT_NONE:
+            dy = torch.empty(dout.shape, dtype=torch.float32, device=dout.device)
+            check(lib.s2i_act_backward(ptr(out), ptr(dout_k), ldd, M, N, ctx.act, ptr(dy), stream()),
+                  "s2i_act_backward")
+        else:
+            dy = dout_k if ldd == N else dout_k.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            packed = packed_weight(weight, PACK_PLAIN)
+            dx = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            dw = _wgrad(ctx.kind_name, x, None, dy, weight.shape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            part = torch.empty((2, 1, N), dtype=torch.float32, device=dy.device)
+            check(lib.s2i_colstats(ptr(dy), M, N, N, ptr(part), 1, stream()), "s2i_colstats")
+            db = part[0, 0, :weight.shape[0]].clone()
+        return dx, dw, db, None, None, None
+
+
+# ---- CA_NET pieces -----------------------------------------------------------------------------------------
+class Glu2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib_ready()
+        x = x.contiguous()
+        M, C = x.shape
+        out = torch.empty((M, C // 2), dtype=torch.float32, device=x.device)
+        check(lib.s2i_glu_forward(ptr(x), M, C, ptr(out), stream()), "s2i_glu_forward")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib_ready()
+        (x,) = ctx.saved_tensors
+        M, C = x.shape
+        dx = torch.empty_like(x)
+        check(lib.s2i_glu_backward(ptr(x), ptr(dout.contiguous()), M, C, ptr(dx), stream()), "s2i_glu_backward")
+        return dx
+
+
+class Reparam(torch.autograd.Function):
+    """h = [mu | logvar] (B, 2E), eps (B, E) -> c = eps*exp(0.5*logvar) + mu  (model.py:188-195)."""
+
+    @staticmethod
+    def forward(ctx, h, eps):
+        lib = _lib_ready()
+        h = h.contiguous()
+        eps = eps.contiguous()
+        B, E2 = h.shape
+        c = torch.empty((B, E2 // 2), dtype=torch.float32, device=h.device)
+        check(lib.s2i_reparam_forward(ptr(h), ptr(eps), B, E2 // 2, ptr(c), stream()), "s2i_reparam_forward")
+        ctx.save_for_backward(h, eps)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        lib = _lib_ready()
+        h, eps = ctx.saved_tensors
+        B, E2 = h.shape
+        dh = torch.empty_like(h)
+        check(lib.s2i_reparam_backward(ptr(h), ptr(eps), ptr(dc.contiguous()), None, None, B, E2 // 2, ptr(dh),
+                                       stream()), "s2i_reparam_backward")
+        return dh, None
+
+
+class KLLoss(torch.autograd.Function):
+    """KL_loss of trainer.py:54-58 on (mu, logvar), each (B, E), possibly column slices of one tensor."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar):
+        lib = _lib_ready()
+        if mu.stride(1) != 1:
+            mu = mu.contiguous()
+        if logvar.stride(1) != 1:
+            logvar = logvar.contiguous()
+        B, E = mu.shape
+        kl = torch.empty((), dtype=torch.float32, device=mu.device)
+        check(lib.s2i_kl_forward(ptr(mu), mu.stride(0), ptr(logvar), logvar.stride(0), B, E, ptr(kl), stream()),
+              "s2i_kl_forward")
+        ctx.save_for_backward(mu, logvar)
+        return kl
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib_ready()
+        mu, logvar = ctx.saved_tensors
+        B, E = mu.shape
+        dmu = torch.empty((B, E), dtype=torch.float32, device=mu.device)
+        dlv = torch.empty((B, E), dtype=torch.float32, device=mu.device)
+        check(lib.s2i_kl_backward(ptr(mu), mu.stride(0), ptr(logvar), logvar.stride(0), B, E, ptr(g.contiguous()),
+                                  ptr(dmu), ptr(dlv), stream()), "s2i_kl_backward")
+        return dmu, dlv
+
+
+# ---- D heads and losses ---------------------------------------------------------------------------------------
+class LogitHead(torch.autograd.Function):
+    """Conv2d(C,1,k=4,s=4)+Sigmoid on a (B,4,4,C) NHWC map (model.py:414-422)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib_ready()
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        if H != 4 or W != 4 or tuple(weight.shape) != (1, C, 4, 4):
+            raise _lib.S2IError("LogitHead: expects a 4x4 map and a (1,C,4,4) weight")
+        prob = torch.empty((B,), dtype=torch.float32, device=x.device)
+        check(lib.s2i_logit_forward(ptr(x), ptr(weight.contiguous()), ptr(bias), B, C, ptr(prob), stream()),
+              "s2i_logit_forward")
+        ctx.save_for_backward(x, weight, prob)
+        ctx.has_bias = bias is not None
+        return prob
+
+    @staticmethod
+    def backward(ctx, dprob):
+        lib = _lib_ready()
+        x, weight, prob = ctx.saved_tensors
+        B, _, _, C = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
+        db = torch.empty((1,), dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        check(lib.s2i_logit_backward(ptr(x), ptr(weight.contiguous()), ptr(prob), ptr(dprob.contiguous()), B, C,
+                                     ptr(dx), 0, ptr(dw), ptr(db), 0, stream()), "s2i_logit_backward")
+        return dx, dw, db
+
+
+class BCELoss(torch.autograd.Function):
+    """weight * nn.BCELoss()(prob, full(target)) (trainer.py:394-409, 439-443)."""
+
+    @staticmethod
+    def forward(ctx, prob, target, weight):
+        lib = _lib_ready()
+        prob = prob.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=prob.device)
+        check(lib.s2i_bce_forward(ptr(prob), float(target), prob.numel(), float(weight), ptr(loss), 0, stream()),
+              "s2i_bce_forward")
+        ctx.save_for_backward(prob)
+        ctx.target, ctx.weight = float(target), float(weight)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib_ready()
+        (prob,) = ctx.saved_tensors
+        dprob = torch.empty_like(prob)
+        check(lib.s2i_bce_backward(ptr(prob), ctx.target, prob.numel(), ctx.weight, ptr(g.contiguous()), ptr(dprob),
+                                   stream()), "s2i_bce_backward")
+        return dprob, None, None
+
+
+class ClassAwareLoss(torch.autograd.Function):
+    """class_aware_loss of trainer.py:298-311 on features (B, D) and int32 device labels (B,)."""
+
+    @staticmethod
+    def forward(ctx, feats, labels):
+        lib = _lib_ready()
+        feats = feats.contiguous()
+        B, D = feats.shape
+        x4 = feats.view(B, 1, 1, D)
+        # scores = X X^T through the implicit-GEMM kernel: the second operand is X itself, read transposed
+        scores, _, _ = conv_raw(CONV_K1, x4, None, feats, B, wmode=1, wR=B, ldw=D)
+        loss = torch.empty((1,), dtype=torch.float32, device=feats.device)
+        dS = torch.empty((B, B), dtype=torch.float32, device=feats.device)
+        check(lib.s2i_cal_loss(ptr(scores), ptr(labels), B, D, ptr(loss), 0, ptr(dS), stream()), "s2i_cal_loss")
+        ctx.save_for_backward(feats, dS)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        feats, dS = ctx.saved_tensors
+        B, D = feats.shape
+        if B % 4 != 0:
+            raise _lib.S2IError("ClassAwareLoss.backward: batch must be a multiple of 4")
+        # dX = dS_sym X : K1 conv with gathered operand dS (B x B) and weights X used as P[k][n]
+        dX, _, _ = conv_raw(CONV_K1, dS.view(B, 1, 1, B), None, feats, D, wmode=0, wR=B, ldw=D)
+        dX = dX.view(B, D)
+        lib = _lib_ready()
+        # scale by the incoming gradient, read on the device (no host sync)
+        check(lib.s2i_scale_dev(ptr(dX), ptr(dX), dX.numel(), ptr(g.contiguous()), stream()), "s2i_scale_dev")
+        return dX, None
+
+
+# ---- layout ---------------------------------------------------------------------------------------------------------
+class ToNHWC(torch.autograd.Function):
+    """(B,C,H,W) -> (B,H,W,Cp) with zero-filled padding channels."""
+
+    @staticmethod
+    def forward(ctx, x, Cp):
+        lib = _lib_ready()
+        x = x.contiguous()
+        B, C, H, W = x.shape
+        out = torch.empty((B, H, W, Cp), dtype=torch.float32, device=x.device)
+        check(lib.s2i_nchw_to_nhwc(ptr(x), ptr(out), B, C, H, W, Cp, stream()), "s2i_nchw_to_nhwc")
+        ctx.C = C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib_ready()
+        dk, ld = _rows_view(dout)
+        B, H, W, _ = dout.shape
+        dx = torch.empty((B, ctx.C, H, W), dtype=torch.float32, device=dout.device)
+        check(lib.s2i_nhwc_to_nchw(ptr(dk), ld, ptr(dx), B, ctx.C, H, W, stream()), "s2i_nhwc_to_nchw")
+        return dx, None
+
+
+class ToNCHW(torch.autograd.Function):
+    """(B,H,W,Cp) -> (B,C,H,W), dropping padding channels."""
+
+    @staticmethod
+    def forward(ctx, x, C):
+        lib = _lib_ready()
+        xk, ld = _rows_view(x)
+        B, H, W, Cp = x.shape
+        out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+        check(lib.s2i_nhwc_to_nchw(ptr(xk), ld, ptr(out), B, C, H, W, stream()), "s2i_nhwc_to_nchw")
+        ctx.Cp = Cp
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib_ready()
+        dout = dout.contiguous()
+        B, C, H, W = dout.shape
+        dx = torch.empty((B, H, W, ctx.Cp), dtype=torch.float32, device=dout.device)
+        check(lib.s2i_nchw_to_nhwc(ptr(dout), ptr(dx), B, C, H, W, ctx.Cp, stream()), "s2i_nchw_to_nhwc")
+        return dx, None
+
+
+# ---- optimiser -----------------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step=0, step_dev=None, gscale=1.0):
+    lib = _lib_ready()
+    check(lib.s2i_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, int(step),
+                            ptr(step_dev), gscale, stream()), "s2i_adam_step")
+
+
+def ema_update(avg, p, decay):
+    lib = _lib_ready()
+    check(lib.s2i_ema_update(ptr(avg), ptr(p), p.numel(), decay, stream()), "s2i_ema_update")
+
+
+def increment(counter):
+    lib = _lib_ready()
+    check(lib.s2i_increment(ptr(counter), stream()), "s2i_increment")
+
+
+def scale_(t, a):
+    lib = _lib_ready()
+    check(lib.s2i_axpby(ptr(t), ptr(t), t.numel(), a, 0.0, stream()), "s2i_axpby")

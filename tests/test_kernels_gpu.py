@@ -1,0 +1,296 @@
+"""Per-operator parity of the HIP kernels (through the C-ABI) against plain torch fp32 on the CPU.
+
+Tolerance: the north-star bound rtol=1e-3 / atol=1e-4 is for the 256x256 outputs of the whole
+network; single operators are held to a tighter rtol=2e-4 / atol=2e-5 (fp32 MFMA is an exact fma
+chain; only summation order differs from MKLDNN).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, rtol=RTOL, atol=ATOL, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-30
+    err = (a - b).abs()
+    bound = atol * max(1.0, scale) + rtol * b.abs()
+    bad = err > bound
+    assert not bad.any(), "%s: max err %.3e (ref scale %.3e), %d/%d out of tolerance" % (
+        what, err.max().item(), scale, int(bad.sum()), bad.numel())
+
+
+def ref_block(x, cvec, w, gamma, beta, residual, kind, act, bias=None):
+    """Reference restatement with stock torch ops, NCHW (model.py:125-169, 358-376)."""
+    if cvec is not None:
+        B, _, H, W = x.shape
+        x = torch.cat((cvec.view(B, -1, 1, 1).repeat(1, 1, H, W), x), 1)
+    if kind == "up":
+        y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    elif kind == "k3s1":
+        y = F.conv2d(x, w, padding=1)
+    elif kind == "k4s2":
+        y = F.conv2d(x, w, stride=2, padding=1)
+    else:
+        y = F.conv2d(x, w.view(w.shape[0], w.shape[1], 1, 1))
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if gamma is not None:
+        y = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    if act == "glu":
+        c = y.shape[1] // 2
+        y = y[:, :c] * torch.sigmoid(y[:, c:])
+    elif act == "lrelu":
+        y = F.leaky_relu(y, 0.2)
+    elif act == "tanh":
+        y = torch.tanh(y)
+    if residual is not None:
+        y = y + residual
+    return y
+
+
+ACT = {"none": 0, "glu": 1, "lrelu": 2, "tanh": 3}
+
+CASES = [
+    # kind, B, H, Cx, Cc, Cout, act, residual
+    ("k3s1", 2, 8, 16, 0, 32, "glu", False),
+    ("k3s1", 3, 16, 8, 8, 24, "glu", False),      # broadcast vector concatenated first
+    ("k3s1", 2, 8, 16, 0, 16, "none", True),       # ResBlock second half
+    ("k3s1", 4, 4, 160, 0, 64, "lrelu", False),    # D tail: tiny map, big K -> split-K
+    ("k3s1", 4, 4, 128, 32, 64, "lrelu", False),   # D jointConv with c_code
+    ("k4s2", 2, 16, 8, 0, 16, "lrelu", False),
+    ("k4s2", 4, 8, 192, 0, 256, "lrelu", False),   # split-K + BN stats via colstats
+    ("up", 2, 4, 32, 0, 32, "glu", False),
+    ("up", 3, 8, 16, 0, 8, "glu", False),
+    ("up", 2, 32, 8, 0, 8, "glu", False),
+    ("k1", 4, 1, 12, 16, 64, "glu", False),        # INIT_STAGE_G.fc: cat(c_code, z) -> Linear -> BN1d -> GLU
+    ("k3s1", 2, 64, 8, 0, 8, "glu", False),        # many row tiles -> multi-part statistics
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv_bn_act_fwd_bwd(gpu, case):
+    from speech_to_image_translation_without_text_amd import ops
+    kind, B, H, Cx, Cc, Cout, act, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    kk = {"k3s1": 3, "k4s2": 4, "up": 3, "k1": 1}[kind]
+    x = torch.randn(B, Cx, H, H, generator=g)
+    cvec = torch.randn(B, Cc, generator=g) if Cc else None
+    w = torch.randn(Cout, Cx + Cc, kk, kk, generator=g) * (1.0 / (kk * (Cx + Cc) ** 0.5))
+    if kind == "k1":
+        w = w.view(Cout, Cx + Cc)
+    gamma = 1 + 0.1 * torch.randn(Cout, generator=g)
+    beta = 0.1 * torch.randn(Cout, generator=g)
+    Ho = {"k3s1": H, "k4s2": H // 2, "up": 2 * H, "k1": H}[kind]
+    Cact = Cout // 2 if act == "glu" else Cout
+    res = torch.randn(B, Cact, Ho, Ho, generator=g) if use_res else None
+    gout = torch.randn(B, Cact, Ho, Ho, generator=g)
+
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (x, cvec, w, gamma, beta, res)]
+    ref = ref_block(*leaves, kind, act)
+    ref.backward(gout)
+
+    dl = [t.clone().to(gpu).requires_grad_(True) if t is not None else None for t in (x, cvec, w, gamma, beta, res)]
+    xg = nhwc(dl[0].detach()).requires_grad_(True)
+    resg = nhwc(dl[5].detach()).requires_grad_(True) if use_res else None
+    rm = torch.zeros(Cout, device=gpu)
+    rv = torch.ones(Cout, device=gpu)
+    nbt = torch.zeros((), dtype=torch.long, device=gpu)
+    out = ops.ConvBnAct.apply(xg, dl[1], dl[2], dl[3], dl[4], resg, kind, ACT[act], (rm, rv, nbt), True)
+    out.backward(nhwc(gout.to(gpu)))
+    torch.cuda.synchronize()
+
+    close(nchw(out), ref, what="out")
+    close(nchw(xg.grad), leaves[0].grad, what="dx")
+    if Cc:
+        close(dl[1].grad, leaves[1].grad, what="dcvec")
+    close(dl[2].grad, leaves[2].grad, what="dw")
+    close(dl[3].grad, leaves[3].grad, what="dgamma", atol=1e-4)
+    close(dl[4].grad, leaves[4].grad, what="dbeta", atol=1e-4)
+    if use_res:
+        close(nchw(resg.grad), leaves[5].grad, what="dres")
+    # running statistics follow torch's momentum rule with the unbiased variance
+    with torch.no_grad():
+        xin = leaves[0] if cvec is None else torch.cat(
+            (leaves[1].view(B, -1, 1, 1).repeat(1, 1, H, H), leaves[0]), 1)
+        yraw = ref_block(xin, None, leaves[2], None, None, None, kind, "none")
+        m = yraw.transpose(0, 1).reshape(Cout, -1)
+        close(rm, 0.1 * m.mean(1), what="running_mean", atol=1e-5)
+        close(rv, 0.9 + 0.1 * m.var(1, unbiased=True), what="running_var", atol=1e-5)
+    assert int(nbt.item()) == 1
+
+
+CONVACT = [
+    # kind, B, H, Cin(true), Cin padded, Cout(true), n_out, act, bias
+    ("k4s2", 2, 16, 3, 4, 16, 16, "lrelu", False),   # first D conv on an NHWC4 image
+    ("k3s1", 2, 16, 16, 16, 3, 4, "tanh", False),    # GET_IMAGE_G -> NHWC4 image
+    ("k1", 4, 1, 64, 64, 32, 32, "none", True),      # CA_NET.fc
+]
+
+
+@pytest.mark.parametrize("case", CONVACT, ids=lambda c: "-".join(str(v) for v in c))
+def test_conv_act_fwd_bwd(gpu, case):
+    from speech_to_image_translation_without_text_amd import ops
+    kind, B, H, Cin, Cinp, Cout, n_out, act, use_bias = case
+    g = torch.Generator().manual_seed(7)
+    kk = {"k3s1": 3, "k4s2": 4, "k1": 1}[kind]
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, kk, kk, generator=g) * 0.2
+    if kind == "k1":
+        w = w.view(Cout, Cin)
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    Ho = H // 2 if kind == "k4s2" else H
+    gout = torch.randn(B, Cout, Ho, Ho, generator=g)
+    xl, wl = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    bl = bias.clone().requires_grad_(True) if use_bias else None
+    ref = ref_block(xl, None, wl, None, None, None, kind, act, bias=bl)
+    ref.backward(gout)
+
+    xp = torch.zeros(B, Cinp, H, H)
+    xp[:, :Cin] = x
+    xg = nhwc(xp).to(gpu).requires_grad_(True)
+    wg = w.to(gpu).requires_grad_(True)
+    bg = bias.to(gpu).requires_grad_(True) if use_bias else None
+    out = ops.ConvAct.apply(xg, wg, bg, kind, ACT[act], n_out)
+    gp = torch.zeros(B, n_out, Ho, Ho)
+    gp[:, :Cout] = gout
+    out.backward(nhwc(gp).to(gpu))
+    torch.cuda.synchronize()
+    close(nchw(out)[:, :Cout], ref, what="out")
+    if n_out > Cout:
+        assert float(nchw(out.detach())[:, Cout:].abs().max()) == 0.0
+    close(nchw(xg.grad)[:, :Cin], xl.grad, what="dx")
+    close(wg.grad, wl.grad, what="dw")
+    if use_bias:
+        close(bg.grad, bl.grad, what="dbias")
+
+
+def test_heads_and_losses(gpu):
+    from speech_to_image_translation_without_text_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C = 8, 32
+    x = torch.randn(B, C, 4, 4, generator=g) * 0.3
+    w = torch.randn(1, C, 4, 4, generator=g) * 0.1
+    b = torch.randn(1, generator=g)
+    xl, wl, bl = (t.clone().requires_grad_(True) for t in (x, w, b))
+    p = torch.sigmoid(F.conv2d(xl, wl, bl, stride=4)).view(-1)
+    loss = F.binary_cross_entropy(p, torch.ones(B)) + 0.5 * F.binary_cross_entropy(p, torch.zeros(B))
+    loss.backward()
+
+    xg = nhwc(x).to(gpu).requires_grad_(True)
+    wg, bg = w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    pg = ops.LogitHead.apply(xg, wg, bg)
+    lg = ops.BCELoss.apply(pg, 1.0, 1.0) + ops.BCELoss.apply(pg, 0.0, 0.5)
+    lg.backward()
+    torch.cuda.synchronize()
+    close(pg, p, what="prob")
+    close(lg, loss, what="bce")
+    close(nchw(xg.grad), xl.grad, what="dx")
+    close(wg.grad, wl.grad, what="dw")
+    close(bg.grad, bl.grad, what="dbias")
+
+
+def ref_class_aware(x, labels):
+    """trainer.py:298-311 restated with boolean masks."""
+    B, D = x.shape
+    scores = x @ x.t()
+    lab = torch.as_tensor(labels)
+    pair = (lab[:, None] == lab[None, :]) & ~torch.eye(B, dtype=torch.bool)
+    if pair.sum() > 0:
+        return torch.clamp(scores.mean() - scores[pair].mean(), min=0).div(D).view(1)
+    return torch.zeros(1)
+
+
+@pytest.mark.parametrize("labels", [[0, 1, 2, 0, 1, 2, 0, 1], [0, 1, 2, 3, 4, 5, 6, 7], [0] * 8])
+def test_class_aware_loss(gpu, labels):
+    from speech_to_image_translation_without_text_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, D = 8, 512
+    x = torch.randn(B, D, generator=g)
+    # make same-class rows anti-correlated so that the hinge is active for the first label set
+    xl = x.clone().requires_grad_(True)
+    ref = ref_class_aware(xl, labels) * 3.0
+    if ref.requires_grad:
+        ref.backward()
+    xg = x.to(gpu).requires_grad_(True)
+    lab = torch.tensor(labels, dtype=torch.int32, device=gpu)
+    out = ops.ClassAwareLoss.apply(xg, lab) * 3.0
+    out.backward()
+    torch.cuda.synchronize()
+    close(out, ref, what="cal")
+    close(xg.grad, xl.grad if xl.grad is not None else torch.zeros_like(x), what="dX")
+
+
+def test_ca_net_pieces(gpu):
+    from speech_to_image_translation_without_text_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, E = 6, 16
+    pre = torch.randn(B, 4 * E, generator=g)
+    eps = torch.randn(B, E, generator=g)
+    pl = pre.clone().requires_grad_(True)
+    h = pl[:, :2 * E] * torch.sigmoid(pl[:, 2 * E:])
+    mu, lv = h[:, :E], h[:, E:]
+    c = eps * torch.exp(0.5 * lv) + mu
+    kl = torch.mean(1 + lv - mu.pow(2) - lv.exp()) * -0.5
+    gc = torch.randn(B, E, generator=g)
+    ((c * gc).sum() + 2.0 * kl + (mu * 0.3).sum()).backward()
+
+    pg = pre.to(gpu).requires_grad_(True)
+    hg = ops.Glu2d.apply(pg)
+    mug, lvg = hg[:, :E], hg[:, E:]
+    cg = ops.Reparam.apply(hg, eps.to(gpu))
+    klg = ops.KLLoss.apply(mug, lvg)
+    ((cg * gc.to(gpu)).sum() + 2.0 * klg + (mug * 0.3).sum()).backward()
+    torch.cuda.synchronize()
+    close(cg, c, what="c")
+    close(klg, kl, what="kl")
+    close(pg.grad, pl.grad, what="dpre")
+
+
+def test_layout_and_optimizer(gpu):
+    from speech_to_image_translation_without_text_amd import ops
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(2, 3, 16, 16, generator=g)
+    ig = img.to(gpu).requires_grad_(True)
+    n = ops.ToNHWC.apply(ig, 4)
+    assert n.shape == (2, 16, 16, 4)
+    close(n[..., :3], img.permute(0, 2, 3, 1), what="nhwc4")
+    assert float(n[..., 3].abs().max()) == 0.0
+    back = ops.ToNCHW.apply(n, 3)
+    close(back, img, what="roundtrip")
+    back.backward(torch.ones_like(back))
+    close(ig.grad, torch.ones_like(img), what="layout grad")
+
+    # fused Adam against torch.optim.Adam, 3 steps, odd length
+    p0 = torch.randn(1003, generator=g)
+    grads = [torch.randn(1003, generator=g) for _ in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999))
+    for gr in grads:
+        pr.grad = gr.clone()
+        opt.step()
+    p = p0.to(gpu)
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=gpu)
+    for i, gr in enumerate(grads):
+        ops.increment(step_dev)
+        ops.adam_step(p, gr.to(gpu), m, v, 2e-4, 0.5, 0.999, 1e-8, step_dev=step_dev)
+    torch.cuda.synchronize()
+    close(p, pr, what="adam", rtol=1e-5, atol=1e-6)
+    avg = p0.to(gpu).clone()
+    ops.ema_update(avg, p, 0.999)
+    close(avg, 0.999 * p0 + 0.001 * p.cpu(), what="ema", rtol=1e-6, atol=1e-6)
