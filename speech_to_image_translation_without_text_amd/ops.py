@@ -59,36 +59,39 @@ def _roundup4(v):
 
 
 # ---- packed weights ------------------------------------------------------------------------------
-class _PackCache:
-    """OIHW parameter -> P[tap][Ip][Op]; refreshed when the parameter's version changes."""
-
-    def __init__(self):
-        self.entries = {}
-
-    def get(self, w, mode):
-        key = (id(w), mode)
-        ent = self.entries.get(key)
-        ver = w._version
-        if (ent is not None and ent[3] is w and ent[1] == ver and ent[2] == w.data_ptr()
-                and ent[0].device == w.device):
-            return ent[0]
-        packed = ent[0] if ent is not None and ent[0].device == w.device else None
-        packed = pack_weight(w, mode, out=packed)
-        self.entries[key] = (packed, ver, w.data_ptr(), w)
-        return packed
-
-    def refresh(self, params):
-        """Re-pack after an in-place update that bypassed torch's version counter (fused Adam)."""
-        ids = {id(p) for p in params}
-        for (pid, mode), ent in list(self.entries.items()):
-            if pid in ids:
-                pack_weight(ent[3], mode, out=ent[0])
-
-    def clear(self):
-        self.entries.clear()
+# OIHW parameter -> P[tap][Ip][Op].  The packed copy lives ON the parameter object (attribute
+# `_s2i_packs`), so it dies with the parameter and can never be mistaken for another network's; it is
+# refreshed when torch's version counter or the storage address changes, or explicitly after an update
+# that bypasses the version counter (the fused Adam kernel).
+def packed_weight(w, mode=0):
+    packs = getattr(w, '_s2i_packs', None)
+    if packs is None:
+        packs = {}
+        w._s2i_packs = packs
+    ent = packs.get(mode)
+    ver, addr = w._version, w.data_ptr()
+    if ent is not None and ent[1] == ver and ent[2] == addr and ent[0].device == w.device:
+        return ent[0]
+    out = ent[0] if ent is not None and ent[0].device == w.device else None
+    packed = pack_weight(w, mode, out=out)
+    packs[mode] = (packed, ver, addr)
+    return packed
 
 
-_packs = _PackCache()
+def refresh_packed(params):
+    """Re-pack every cached layout of these parameters in place."""
+    for p in params:
+        packs = getattr(p, '_s2i_packs', None)
+        if packs:
+            for mode, ent in list(packs.items()):
+                if ent[0].device == p.device:
+                    packs[mode] = (pack_weight(p, mode, out=ent[0]), p._version, p.data_ptr())
+                else:
+                    del packs[mode]
+
+
+def clear_caches():
+    pass
 
 
 def pack_weight(w, mode, out=None):
@@ -106,18 +109,6 @@ def pack_weight(w, mode, out=None):
         out = torch.empty((T, Ip, Op), dtype=torch.float32, device=w.device)
     check(lib.s2i_pack_conv_weight(ptr(w), ptr(out), O, I, KH, KW, Ip, mode, stream()), "s2i_pack_conv_weight")
     return out
-
-
-def packed_weight(w, mode=PACK_PLAIN):
-    return _packs.get(w, mode)
-
-
-def refresh_packed(params):
-    _packs.refresh(list(params))
-
-
-def clear_caches():
-    _packs.clear()
 
 
 # ---- raw kernels ------------------------------------------------------------------------------------

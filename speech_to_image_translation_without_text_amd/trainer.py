@@ -1,0 +1,380 @@
+"""Train-step harness with the surface of the reference's StackGAN_v2/trainer.py, on the MI355X kernels.
+
+Same names and meaning as the reference where a caller can see them:
+  weights_init (:65-75), load_params / copy_G_params (:78-85), KL_loss (:54-58),
+  class_aware_loss (:298-311), load_network (:162-233), define_optimizers (:236-252),
+  save_model (:255-265), condGANTrainer(output_dir, data_loader, imsize, my_dataset_flag,
+  local_rank, distributed) with prepare_data / train_Dnet / train_Gnet / train (:318-638).
+
+What is built differently (MI355X-first):
+  * every network's parameters, gradients and Adam moments live in ONE flat fp32 buffer each, so the
+    optimiser is a single fused kernel per network (Adam, plus the EMA of G), and data-parallel
+    training is one RCCL all-reduce per network over xGMI instead of DDP's bucket stream;
+  * the three D updates are independent, so D_i's all-reduce overlaps D_{i+1}'s forward/backward;
+  * the G update does not compute (and never reduces) the discriminators' weight gradients the
+    reference's backward produces and then discards (trainer.py:385 zeroes them);
+  * per-replica BatchNorm statistics and per-replica class-aware loss, as in the reference's DDP.
+The Inception-v3 forwards, IS/FID and image dumps of the reference loop are evaluation-side and out
+of scope; the loop here runs the update and the checkpoint layout only.
+"""
+import os
+import time
+from copy import deepcopy
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .miscc.config import cfg
+from .miscc.utils import mkdir_p
+from .model import D_NET64, D_NET128, D_NET256, D_NET512, D_NET1024, G_NET, INCEPTION_V3  # noqa: F401
+
+
+# ---- shared functions --------------------------------------------------------------------------------
+def KL_loss(mu, logvar):
+    return ops.KLLoss.apply(mu, logvar)
+
+
+def weights_init(m):
+    """Conv*/Linear: orthogonal(gain 1); BatchNorm*: weight ~ N(1, 0.02), bias 0 (trainer.py:65-75)."""
+    classname = m.__class__.__name__
+    if classname.find('Conv') != -1:
+        nn.init.orthogonal_(m.weight.data, 1.0)
+    elif classname.find('BatchNorm') != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+    elif classname.find('Linear') != -1:
+        nn.init.orthogonal_(m.weight.data, 1.0)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+
+
+def load_params(model, new_param):
+    for p, new_p in zip(model.parameters(), new_param):
+        p.data.copy_(new_p)
+    ops.refresh_packed(model.parameters())
+
+
+def copy_G_params(model):
+    return deepcopy(list(p.data for p in model.parameters()))
+
+
+def class_labels_to_device(class_labels, device):
+    if torch.is_tensor(class_labels):
+        return class_labels.to(device=device, dtype=torch.int32).contiguous()
+    return torch.tensor([int(v) for v in class_labels], dtype=torch.int32, device=device)
+
+
+def class_aware_loss(x_activates, class_labels):
+    """x_activates (B, D); class_labels: sequence / tensor of B class ids (trainer.py:298-311)."""
+    return ops.ClassAwareLoss.apply(x_activates, class_labels_to_device(class_labels, x_activates.device))
+
+
+def _unwrap(net):
+    return net.module if hasattr(net, 'module') else net
+
+
+class _Replica(nn.Module):
+    """Stand-in for the reference's DataParallel / DDP wrapper: same `module.`-prefixed state_dict
+    keys (trainer.py:167-171, 192-196, 255-265) and a `device_ids` attribute, no comm of its own —
+    gradients are reduced per network by FlatNet below."""
+
+    def __init__(self, module, device_ids):
+        super().__init__()
+        self.module = module
+        self.device_ids = list(device_ids)
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def load_network(gpus, distributed):
+    """Build G and the per-scale Ds, initialise, wrap, optionally resume (trainer.py:162-233).
+    The reference also builds INCEPTION_V3 here (a network download); the returned slot is None."""
+    dev = torch.device('cuda', gpus[0]) if cfg.CUDA else torch.device('cpu')
+    netG = G_NET()
+    netG.apply(weights_init)
+    netG = _Replica(netG.to(dev), gpus)
+    classes = (D_NET64, D_NET128, D_NET256, D_NET512, D_NET1024)
+    netsD = []
+    for i in range(min(cfg.TREE.BRANCH_NUM, len(classes))):
+        d = classes[i]()
+        d.apply(weights_init)
+        netsD.append(_Replica(d.to(dev), gpus))
+    count = 0
+    if cfg.TRAIN.NET_G != '':
+        state_dict = torch.load(cfg.TRAIN.NET_G, map_location='cpu', weights_only=True)
+        netG.load_state_dict(state_dict)
+        istart = cfg.TRAIN.NET_G.rfind('_') + 1
+        iend = cfg.TRAIN.NET_G.rfind('.')
+        count = int(cfg.TRAIN.NET_G[istart:iend]) + 1
+    if cfg.TRAIN.NET_D != '':
+        for i in range(len(netsD)):
+            state_dict = torch.load('%s%d.pth' % (cfg.TRAIN.NET_D, i), map_location='cpu', weights_only=True)
+            netsD[i].load_state_dict(state_dict)
+    return netG, netsD, len(netsD), None, count
+
+
+# ---- flat parameter storage + fused optimiser -------------------------------------------------------------
+class FlatNet:
+    """All parameters of one network re-homed into a flat buffer (views keep nn.Module semantics);
+    gradients accumulate into a second flat buffer; Adam moments in two more."""
+
+    def __init__(self, net, lr, betas=(0.5, 0.999), eps=1e-8, with_ema=False):
+        self.net = net
+        self.params = [p for p in net.parameters()]
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        self.offsets, off = [], 0
+        for n in self.sizes:
+            self.offsets.append(off)
+            off += (n + 3) & ~3  # keep every tensor 16-byte aligned inside the flat buffer
+        self.total = off
+        self.p = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            self.p[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.p[o:o + n].view_as(p)
+            p.grad = self.g[o:o + n].view_as(p)
+        self.avg = self.p.clone() if with_ema else None
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_count = 0
+        ops.refresh_packed(self.params)
+
+    def zero_grad(self):
+        self.g.zero_()
+        for p, o, n in zip(self.params, self.offsets, self.sizes):
+            if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
+                p.grad = self.g[o:o + n].view_as(p)
+
+    def set_requires_grad(self, flag):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+    def adam(self, gscale=1.0):
+        ops.increment(self.step_dev)
+        self.step_count += 1
+        ops.adam_step(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                      step_dev=self.step_dev, gscale=gscale)
+        ops.refresh_packed(self.params)
+
+    def ema(self, decay=0.999):
+        ops.ema_update(self.avg, self.p, decay)
+
+    def avg_params(self):
+        return [self.avg[o:o + n].view_as(p) for p, o, n in zip(self.params, self.offsets, self.sizes)]
+
+
+class _LegacyOptimizer:
+    """`optimizer.step()` / `.zero_grad()` facade over FlatNet for callers written against
+    torch.optim (define_optimizers' return values)."""
+
+    def __init__(self, flat):
+        self.flat = flat
+
+    def step(self):
+        self.flat.adam()
+
+    def zero_grad(self):
+        self.flat.zero_grad()
+
+
+def define_optimizers(netG, netsD):
+    """Adam(lr from cfg, betas (0.5, 0.999)) per network (trainer.py:236-252), fused and flat."""
+    flatsD = [FlatNet(_unwrap(d), cfg.TRAIN.DISCRIMINATOR_LR) for d in netsD]
+    flatG = FlatNet(_unwrap(netG), cfg.TRAIN.GENERATOR_LR, with_ema=True)
+    return _LegacyOptimizer(flatG), [_LegacyOptimizer(f) for f in flatsD]
+
+
+def save_model(netG, avg_param_G, netsD, epoch, model_dir):
+    """Model/netG_<count>.pth holds the EMA weights, Model/netD<i>.pth the live ones; keys carry the
+    wrapper's `module.` prefix (trainer.py:255-265).  Tensors are cloned so the flat buffers behind
+    the parameter views are not serialised whole."""
+    load_params(netG, avg_param_G)
+    torch.save({k: v.clone() for k, v in netG.state_dict().items()}, '%s/netG_%d.pth' % (model_dir, epoch))
+    for i, netD in enumerate(netsD):
+        torch.save({k: v.clone() for k, v in netD.state_dict().items()}, '%s/netD%d.pth' % (model_dir, i))
+    print('Save G/Ds models.')
+
+
+# ---- the trainer -----------------------------------------------------------------------------------------------
+class condGANTrainer(object):
+    def __init__(self, output_dir, data_loader, imsize, my_dataset_flag, local_rank=0, distributed=False):
+        self.my_dataset_flag = my_dataset_flag
+        if output_dir is not None:
+            if not cfg.TRAIN.FLAG:
+                output_dir += "_eval"
+            self.model_dir = os.path.join(output_dir, 'Model')
+            self.image_dir = os.path.join(output_dir, 'Image')
+            self.log_dir = os.path.join(output_dir, 'Log')
+            for d in (self.model_dir, self.image_dir, self.log_dir):
+                mkdir_p(d)
+        self.gpus = [local_rank]
+        self.batch_size = cfg.TRAIN.BATCH_SIZE
+        self.max_epoch = cfg.TRAIN.MAX_EPOCH
+        self.snapshot_interval = cfg.TRAIN.SNAPSHOT_INTERVAL
+        self.data_loader = data_loader
+        self.num_batches = len(data_loader) if data_loader is not None else 0
+        self.distributed = distributed
+        self.world = torch.distributed.get_world_size() if distributed else 1
+        self._pending = []
+
+    # -- set-up -------------------------------------------------------------------------------------------
+    def build(self, netG=None, netsD=None, start_count=0):
+        """Networks + flat optimisers.  `train()` calls this; benches and tests may pass their own nets."""
+        if netG is None:
+            netG, netsD, _, _, start_count = load_network(self.gpus, self.distributed)
+        self.netG, self.netsD, self.num_Ds = netG, netsD, len(netsD)
+        self.optimizerG, self.optimizersD = define_optimizers(self.netG, self.netsD)
+        self.flatG = self.optimizerG.flat
+        self.flatsD = [o.flat for o in self.optimizersD]
+        if self.distributed:
+            for f in [self.flatG] + self.flatsD:  # identical start on every rank (DDP's initial broadcast)
+                torch.distributed.broadcast(f.p, 0)
+                if f.avg is not None:
+                    f.avg.copy_(f.p)
+                ops.refresh_packed(f.params)
+        self.avg_param_G = self.flatG.avg_params()
+        return start_count
+
+    def prepare_data(self, data):
+        if self.my_dataset_flag:
+            imgs, w_imgs, t_embedding = data["real_image"], data["wrong_image"], data["real_embedding"]
+            class_labels = data.get("class_label", data.get("text"))
+        else:
+            imgs, w_imgs, t_embedding, _, class_labels = data
+        dev = torch.device('cuda', self.gpus[0])
+        vembedding = t_embedding.float().to(dev, non_blocking=True).requires_grad_()
+        real_vimgs = [imgs[i].to(dev, non_blocking=True) for i in range(self.num_Ds)]
+        wrong_vimgs = [w_imgs[i].to(dev, non_blocking=True) for i in range(self.num_Ds)]
+        return imgs, real_vimgs, wrong_vimgs, vembedding, class_labels
+
+    # -- communication ------------------------------------------------------------------------------------------
+    def _reduce_async(self, flat):
+        if not self.distributed:
+            return None
+        return torch.distributed.all_reduce(flat.g, op=torch.distributed.ReduceOp.SUM, async_op=True)
+
+    # -- D update (trainer.py:375-427) ----------------------------------------------------------------------------
+    def _d_loss(self, idx):
+        netD = self.netsD[idx]
+        mu = self.mu.detach()
+        u = cfg.TRAIN.COEFF.UNCOND_LOSS
+        real_logits, _ = netD(self.real_imgs[idx], mu)
+        wrong_logits, _ = netD(self.wrong_imgs[idx], mu)
+        fake_logits, _ = netD(self.fake_imgs[idx].detach(), mu)
+        errD_real = ops.BCELoss.apply(real_logits[0], 1.0, 1.0)
+        errD_wrong = ops.BCELoss.apply(wrong_logits[0], 0.0, 1.0)
+        errD_fake = ops.BCELoss.apply(fake_logits[0], 0.0, 1.0)
+        if len(real_logits) > 1 and u > 0:
+            errD_real = errD_real + ops.BCELoss.apply(real_logits[1], 1.0, u)
+            errD_wrong = errD_wrong + ops.BCELoss.apply(wrong_logits[1], 1.0, u)  # uncond target real (:401)
+            errD_fake = errD_fake + ops.BCELoss.apply(fake_logits[1], 0.0, u)
+            return errD_real + errD_wrong + errD_fake
+        return errD_real + 0.5 * (errD_wrong + errD_fake)
+
+    def train_Dnet(self, idx, count, defer_step=False):
+        flat = self.flatsD[idx]
+        flat.zero_grad()
+        errD = self._d_loss(idx)
+        errD.backward()
+        work = self._reduce_async(flat)
+        if defer_step:
+            self._pending.append((flat, work))
+        else:
+            if work is not None:
+                work.wait()
+            flat.adam(1.0 / self.world)
+        return errD
+
+    def _flush_d_steps(self):
+        for flat, work in self._pending:
+            if work is not None:
+                work.wait()
+            flat.adam(1.0 / self.world)
+        self._pending = []
+
+    # -- G update (trainer.py:429-489) ------------------------------------------------------------------------------
+    def train_Gnet(self, count):
+        self.flatG.zero_grad()
+        u = cfg.TRAIN.COEFF.UNCOND_LOSS
+        errG_total = 0
+        errG_cal_total = 0
+        labels_dev = None
+        for f in self.flatsD:
+            f.set_requires_grad(False)  # their weight gradients would be discarded (trainer.py:385)
+        try:
+            for i in range(self.num_Ds):
+                outputs, x_active = self.netsD[i](self.fake_imgs[i], self.mu)
+                errG = ops.BCELoss.apply(outputs[0], 1.0, 1.0)
+                if len(outputs) > 1 and u > 0:
+                    errG = errG + ops.BCELoss.apply(outputs[1], 1.0, u)
+                if cfg.TRAIN.COEFF.CAL_LOSS > 0:
+                    if labels_dev is None:
+                        labels_dev = class_labels_to_device(self.class_labels, x_active.device)
+                    errG_cal_total = errG_cal_total + ops.ClassAwareLoss.apply(x_active, labels_dev)
+                errG_total = errG_total + errG
+            if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
+                raise NotImplementedError("colour-consistency loss (trainer.py:455-478) is dormant in every "
+                                          "BASELINE config and not built on this path")
+            kl_loss = KL_loss(self.mu, self.logvar) * cfg.TRAIN.COEFF.KL
+            errG_total = errG_total + kl_loss + errG_cal_total
+            errG_total.backward()
+        finally:
+            for f in self.flatsD:
+                f.set_requires_grad(True)
+        work = self._reduce_async(self.flatG)
+        if work is not None:
+            work.wait()
+        self.flatG.adam(1.0 / self.world)
+        return kl_loss, errG_total
+
+    # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
+    def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
+        self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
+        self.txt_embedding, self.class_labels = txt_embedding, class_labels
+        self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
+        errD_total = 0
+        for i in range(self.num_Ds):
+            errD_total = errD_total + self.train_Dnet(i, 0, defer_step=True)
+        self._flush_d_steps()
+        kl_loss, errG_total = self.train_Gnet(0)
+        self.flatG.ema(0.999)
+        return errD_total, errG_total, kl_loss
+
+    def train(self):
+        start_count = self.build()
+        dev = torch.device('cuda', self.gpus[0])
+        nz = cfg.GAN.Z_DIM
+        noise = torch.empty(self.batch_size, nz, device=dev)
+        count = start_count
+        start_epoch = start_count // max(self.num_batches, 1)
+        errD_total = errG_total = kl_loss = None
+        for epoch in range(start_epoch, self.max_epoch):
+            start_t = time.time()
+            for step, data in enumerate(self.data_loader, 0):
+                _, real, wrong, emb, labels = self.prepare_data(data)
+                noise.normal_(0, 1)
+                errD_total, errG_total, kl_loss = self.train_step(real, wrong, emb, labels, noise[:emb.shape[0]])
+                if step == 0 and self.gpus[0] == 0:
+                    print('[%d/%d][%d/%d] Loss_D: %.2f Loss_G: %.2f'
+                          % (epoch, self.max_epoch, step, self.num_batches, errD_total.item(), errG_total.item()))
+                count += 1
+                if count % cfg.TRAIN.SNAPSHOT_INTERVAL == 0:
+                    self.save(count)
+            if errD_total is not None and self.gpus[0] == 0:
+                print('[%d/%d][%d] Loss_D: %.2f Loss_G: %.2f Loss_KL: %.2f Time: %.2fs'
+                      % (epoch, self.max_epoch, self.num_batches, errD_total.item(), errG_total.item(),
+                         kl_loss.item(), time.time() - start_t))
+        self.save(count)
+
+    def save(self, count):
+        """The reference overwrites G's live weights with the EMA copy when it saves and never restores
+        them (trainer.py:256, 590-601); the live weights are kept here."""
+        live = self.flatG.p.clone()
+        save_model(self.netG, self.avg_param_G, self.netsD, count, self.model_dir)
+        self.flatG.p.copy_(live)
+        ops.refresh_packed(self.flatG.params)

@@ -1,0 +1,78 @@
+"""Shared test plumbing: golden-case configuration, seeded network construction, synthetic batches."""
+import importlib.util
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+_spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+make_golden = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(make_golden)  # defines functions only; the reference is imported by its main()
+CASES, make_batch, checksum, sample = make_golden.CASES, make_golden.make_batch, make_golden.checksum, make_golden.sample
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def configure(case):
+    """Point the package's global cfg at a golden case (what make_golden.set_cfg does to the reference's)."""
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_reset
+    cfg_reset()
+    cfg.CUDA = torch.cuda.is_available()
+    cfg.TREE.BRANCH_NUM = case['branch']
+    cfg.GAN.GF_DIM, cfg.GAN.DF_DIM = case['gf'], case['df']
+    cfg.GAN.EMBEDDING_DIM, cfg.GAN.Z_DIM, cfg.TEXT.DIMENSION = case['ef'], case['z'], case['t']
+    cfg.GAN.R_NUM, cfg.GAN.B_CONDITION = 2, True
+    cfg.TRAIN.BATCH_SIZE = case['B']
+    cfg.TRAIN.COEFF.UNCOND_LOSS, cfg.TRAIN.COEFF.CAL_LOSS = 1.0, 50.0
+    cfg.TRAIN.COEFF.KL, cfg.TRAIN.COEFF.COLOR_LOSS = 2.0, 0.0
+    cfg.TRAIN.DISCRIMINATOR_LR = cfg.TRAIN.GENERATOR_LR = 2e-4
+    return cfg
+
+
+def build_nets(case):
+    """Seeded construction on the CPU, in the reference's order (trainer.py:163-197)."""
+    from speech_to_image_translation_without_text_amd import model, trainer
+    configure(case)
+    torch.manual_seed(case['seed'])
+    netG = model.G_NET()
+    netG.apply(trainer.weights_init)
+    netsD = []
+    for cls in (model.D_NET64, model.D_NET128, model.D_NET256)[:case['branch']]:
+        d = cls()
+        d.apply(trainer.weights_init)
+        netsD.append(d)
+    return netG, netsD
+
+
+def oracle_dims(case):
+    from oracle import stackgan_oracle as orc
+    return orc.Dims(case['branch'], case['gf'], case['df'], case['ef'], case['z'], case['t'], 2)
+
+
+def assert_close(a, b, rtol=1e-3, atol=1e-4, what=""):
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a.detach().cpu()).double()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b.detach().cpu()).double()
+    assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bool(bad.any()), "%s: max abs err %.3e, %d/%d beyond rtol=%g atol=%g" % (
+        what, float(err.max()), int(bad.sum()), bad.numel(), rtol, atol)
+
+
+def assert_close_l2(a, b, tol, what=""):
+    """||a-b||_2 <= tol * ||b||_2.  Used for gradients that pass LeakyReLU / hinge kinks: the GPU and CPU
+    forward values differ by ~1e-6, so a pre-activation within that distance of zero lands on different
+    sides of the kink on the two devices and flips one mask element (factor 1 vs 0.2).  That is a property
+    of the function, not of the kernels (given bit-identical inputs the backward agrees to ~1e-6, see
+    tests/test_kernels_gpu.py), and it perturbs a dense downstream gradient by a small NORM-wise amount,
+    which an element-wise rtol cannot express."""
+    a = torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a.detach().cpu()).double()
+    b = torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b.detach().cpu()).double()
+    assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
+    num, den = float((a - b).norm()), float(b.norm()) + 1e-30
+    assert num <= tol * den, "%s: relative L2 error %.3e > %.1e" % (what, num / den, tol)

@@ -78,6 +78,15 @@ CASES = [
     ("up", 2, 32, 8, 0, 8, "glu", False),
     ("k1", 4, 1, 12, 16, 64, "glu", False),        # INIT_STAGE_G.fc: cat(c_code, z) -> Linear -> BN1d -> GLU
     ("k3s1", 2, 64, 8, 0, 8, "glu", False),        # many row tiles -> multi-part statistics
+    # full-width D64 layers at batch 4 (BASELINE config 1 shapes)
+    ("k4s2", 4, 32, 64, 0, 128, "lrelu", False),
+    ("k4s2", 4, 16, 128, 0, 256, "lrelu", False),
+    ("k4s2", 4, 8, 256, 0, 512, "lrelu", False),
+    ("k3s1", 4, 4, 512, 128, 512, "lrelu", False),
+    # full-width G layers at batch 4
+    ("k1", 4, 1, 100, 128, 2048, "glu", False),
+    ("up", 4, 4, 1024, 0, 1024, "glu", False),
+    ("up", 4, 32, 128, 0, 128, "glu", False),
 ]
 
 
