@@ -1,0 +1,212 @@
+"""StackGAN-v2 3-stage G+D train-step benchmark on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration of the reference loop body (trainer.py:536-572, Inception excluded):
+G forward, 3x {3 D forwards, 6 BCE terms, backward, all-reduce, Adam}, G update through the updated
+Ds {BCE + class-aware + 2*KL, backward, all-reduce, Adam}, EMA; cfg/birds_3stages.yml, batch 24 per
+GPU, fp32, synthetic inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_IMAGE = 1.4264e11       # algorithmic FLOPs per image per train step, branch_num=3
+BYTES_PER_STEP_B24 = 28.46e9     # algorithmic HBM bytes per B=24 step
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32 vector = f32-MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    return ap.parse_args()
+
+
+def synthetic_batch(B, dev, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    batch = dict(emb=torch.randn(B, 1024, device=dev, generator=g),
+                 labels=(torch.arange(B, device=dev) % 3).to(torch.int32), real=[], wrong=[])
+    for i in range(3):
+        s = 64 << i
+        batch["real"].append(torch.rand(B, 3, s, s, device=dev, generator=g) * 2 - 1)
+        batch["wrong"].append(torch.rand(B, 3, s, s, device=dev, generator=g) * 2 - 1)
+    return batch, g
+
+
+def dominant_kernel_roofline(dev, B):
+    """Live HIP-event timing of the dominant kernel: the fp32-MFMA implicit-GEMM convolution, on the
+    heaviest single layer of the step (D_NET256 img_code_s16[2]: Conv2d(64,128,k4,s2,p1) on 128x128)."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K4S2, PACK_PLAIN
+    x = torch.randn(B, 128, 128, 64, device=dev)
+    w = torch.randn(128, 64, 4, 4, device=dev) * 0.03
+    packed = ops.pack_weight(w, PACK_PLAIN)
+    flops = 2.0 * (B * 64 * 64) * 128 * (16 * 64)
+    for _ in range(3):
+        ops.conv_raw(CONV_K4S2, x, None, packed, 128, wR=64, ldw=128, stats=True)
+    reps = 20
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        ops.conv_raw(CONV_K4S2, x, None, packed, 128, wR=64, ldw=128, stats=True)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "kernel": "igemm_fwd_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32)",
+            "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) NHWC, %.2f GFLOP/launch, %.3f ms" % (B, flops / 1e9, ms)}
+
+
+def cpu_baseline(B):
+    """The CPU oracle (a restatement of the reference's torch-CPU path) timed on this host: one full
+    iteration at branch_num=3, full width."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import CASES, build_nets, make_batch, oracle_dims
+    from oracle import stackgan_oracle as orc
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)  # the GPU box gives one GPU's share of the host: 16 cores
+    torch.set_num_threads(cores)
+    case = dict(CASES["full3_fwd"], B=B)
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    state = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    t0 = time.time()
+    orc.train_step(state, batch, oracle_dims(case))
+    dt = time.time() - t0
+    return {"value": round(B / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 full train iteration (G fwd, 3 D updates, G update, EMA), branch_num=3, batch %d, "
+                      "torch %s CPU fp32, %.1f s" % (B, torch.__version__, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.same_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(args.backend)
+
+    from speech_to_image_translation_without_text_amd import model, trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
+    cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
+    cfg.TRAIN.BATCH_SIZE = args.batch
+    B = args.batch
+
+    torch.manual_seed(0)  # identical initial weights on every rank (and equal to the reference's at seed 0)
+    netG = model.G_NET()
+    netG.apply(T.weights_init)
+    netsD = []
+    for cls in (model.D_NET64, model.D_NET128, model.D_NET256):
+        d = cls()
+        d.apply(T.weights_init)
+        netsD.append(d)
+    netG.to(dev)
+    for d in netsD:
+        d.to(dev)
+    tr = T.condGANTrainer(None, None, 256, False, local_rank=local_rank, distributed=distributed)
+    tr.build(netG, netsD)
+
+    t_start = time.perf_counter()
+    batch, gen = synthetic_batch(B, dev, 1 + rank)
+    noise = torch.empty(B, cfg.GAN.Z_DIM, device=dev)
+    eps = torch.empty(B, cfg.GAN.EMBEDDING_DIM, device=dev)
+
+    def one_step():
+        noise.normal_(generator=gen)
+        eps.normal_(generator=gen)
+        emb = batch["emb"].detach().requires_grad_(True)
+        return tr.train_step(batch["real"], batch["wrong"], emb, batch["labels"], noise, eps)
+
+    def note(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    for i in range(args.warmup):
+        out = one_step()
+        torch.cuda.synchronize()
+        note("warm-up step %d done" % i)
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    if distributed:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = [float(v) for v in out]
+    if not all(abs(v) < 1e6 for v in losses):
+        raise RuntimeError("non-finite losses after the timed region: %s" % losses)
+
+    if rank == 0:
+        note("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
+        ms = elapsed / args.steps * 1e3
+        value = B * world * args.steps / elapsed
+        step_flops = FLOP_PER_IMAGE * B
+        line = {
+            "metric": "StackGAN-v2 3-stage G+D train-step images/sec at 256px",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, fp32, "
+                                   "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise" % B,
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "step_roofline": {
+                "flops_frac": round(step_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
+                "achieved_tflops": round(step_flops / (ms * 1e-3) / 1e12, 2),
+                "hbm_frac_of_8TBs": round(BYTES_PER_STEP_B24 * (B / 24.0) / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                "note": "algorithmic FLOPs 1.4264e11/img/step and bytes 28.46 GB per B=24 step (SURVEY.md §8d); "
+                        "fp32 step is FLOP-bound, so the HBM fraction is capped near 0.21"},
+            "losses": {"errD_total": losses[0], "errG_total": losses[1], "kl": losses[2]},
+        }
+        if world == 1:
+            line["roofline"] = dominant_kernel_roofline(dev, B)
+            if not args.no_cpu_baseline:
+                note("timing the CPU oracle (bounded sample, batch %d)" % args.cpu_baseline_batch)
+                line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)
+                note("CPU oracle done")
+        print(json.dumps(line))
+    if distributed:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
