@@ -428,61 +428,97 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradP p) {
     }
 }
 
-// Reduce the split slabs and scatter into the reference's OIHW gradient tensor.
-// fold: the 3x3 parameter tap (ky,kx) collects the effective 4x4 taps it was summed into.
-__global__ void wgrad_finish_kernel(const float* __restrict__ slab, int S, int K, int N, int Cg, int O,
-                                    int I, int KH, int KW, int swap, int fold, int accumulate,
-                                    float* __restrict__ grad) {
-  const long long total = (long long)O * I * KH * KW;
+// Reduce the split slabs and write the reference's OIHW gradient tensor.  A [T][RT][32] tile goes through
+// LDS so that both the slab reads (32 consecutive columns) and the OIHW writes (runs of (cin, ky, kx) for one
+// cout) are coalesced.  fold: the 3x3 parameter tap (ky,kx) collects the 4 effective 4x4 taps it was summed into.
+//   non-swap: slab rows (tap, cin), columns cout;   swap: slab rows (tap, cout), columns cin.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slab, int S, int K, int N,
+                                                           int Cg, int O, int I, int Tp, int T, int swap, int fold,
+                                                           int accumulate, int RT, float* __restrict__ grad) {
+  extern __shared__ float tile[];  // [T][RT][33]
+  const int tid = threadIdx.x;
+  const int ncols = swap ? I : O, nrows = swap ? O : I;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * RT;
   const size_t sstride = (size_t)K * N;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int kx = (int)(e % KW);
-    const int ky = (int)((e / KW) % KH);
-    const int i = (int)((e / ((long long)KW * KH)) % I);
-    const int o = (int)(e / ((long long)KW * KH * I));
+  const int nload = T * RT * 32;
+  for (int e = tid; e < nload; e += 256) {
+    const int c_l = e & 31;
+    const int r_l = (e >> 5) % RT;
+    const int t = (e >> 5) / RT;
+    const int c = c0 + c_l, r = r0 + r_l;
     float v = 0.f;
-    const int ny = fold ? 2 : 1, nx = fold ? 2 : 1;
-    for (int ay = 0; ay < ny; ++ay)
-      for (int ax = 0; ax < nx; ++ax) {
-        int tap;
-        if (fold) {
-          const int k4y = (2 - ky) + ay, k4x = (2 - kx) + ax;  // ky=0:{2,3} ky=1:{1,2} ky=2:{0,1}
-          tap = k4y * 4 + k4x;
-        } else {
-          tap = ky * KW + kx;
+    if (c < ncols && r < nrows) {
+      const float* sp = slab + ((size_t)t * Cg + r) * N + c;
+      for (int s = 0; s < S; ++s) v += sp[s * sstride];
+    }
+    tile[(t * RT + r_l) * 33 + c_l] = v;
+  }
+  __syncthreads();
+  const int nout = 32 * RT * Tp;
+  for (int w = tid; w < nout; w += 256) {
+    const int tapo = w % Tp;
+    const int rest = w / Tp;
+    int o_l, i_l, r_l, c_l;
+    if (swap) { i_l = rest & 31; o_l = rest >> 5; r_l = o_l; c_l = i_l; }
+    else { i_l = rest % RT; o_l = rest / RT; r_l = i_l; c_l = o_l; }
+    const int o = swap ? r0 + o_l : c0 + o_l;
+    const int i = swap ? c0 + i_l : r0 + i_l;
+    if (o >= O || i >= I) continue;
+    float v;
+    if (fold) {
+      const int ky = tapo / 3, kx = tapo - ky * 3;
+      v = 0.f;
+#pragma unroll
+      for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+        for (int ax = 0; ax < 2; ++ax) {
+          const int t = ((2 - ky) + ay) * 4 + (2 - kx) + ax;  // ky=0:{2,3} ky=1:{1,2} ky=2:{0,1}
+          v += tile[(t * RT + r_l) * 33 + c_l];
         }
-        const size_t off = swap ? ((size_t)tap * Cg + o) * N + i : ((size_t)tap * Cg + i) * N + o;
-        for (int s = 0; s < S; ++s) v += slab[s * sstride + off];
-      }
-    grad[e] = accumulate ? grad[e] + v : v;
+    } else {
+      v = tile[(tapo * RT + r_l) * 33 + c_l];
+    }
+    float* gp = grad + ((size_t)o * I + i) * Tp + tapo;
+    *gp = accumulate ? *gp + v : v;
   }
 }
 
-// OIHW -> packed P[t][i][op]
-__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed, int O, int I,
-                                   int KH, int KW, int Ip, int Op, int T, int mode) {
-  const long long total = (long long)T * Ip * Op;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long long)gridDim.x * blockDim.x) {
-    const int o = (int)(e % Op);
-    const int i = (int)((e / Op) % Ip);
-    const int t = (int)(e / ((long long)Op * Ip));
+// OIHW -> packed P[t][Ip][Op] through an LDS tile of 32 cout x 8 cin x taps: coalesced on both sides.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                                          int O, int I, int Tp, int Ip, int Op, int T, int mode) {
+  extern __shared__ float tile[];  // [32][8*Tp + 1]
+  const int tid = threadIdx.x;
+  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 8;
+  const int ostride = 8 * Tp + 1;
+  const int nload = 32 * 8 * Tp;
+  for (int e = tid; e < nload; e += 256) {
+    const int tapo = e % Tp;
+    const int i_l = (e / Tp) & 7;
+    const int o_l = e / (Tp * 8);
+    const int o = o0 + o_l, i = i0 + i_l;
+    tile[o_l * ostride + i_l * Tp + tapo] = (o < O && i < I) ? w[((size_t)o * I + i) * Tp + tapo] : 0.f;
+  }
+  __syncthreads();
+  const int nout = T * 8 * 32;
+  for (int e = tid; e < nout; e += 256) {
+    const int o_l = e & 31;
+    const int i_l = (e >> 5) & 7;
+    const int t = e >> 8;
+    const int o = o0 + o_l, i = i0 + i_l;
+    if (o >= Op || i >= Ip) continue;
+    const float* tp = tile + o_l * ostride + i_l * Tp;
     float v = 0.f;
-    if (o < O && i < I) {
-      const float* wp = w + ((size_t)o * I + i) * KH * KW;
-      if (mode == S2I_PACK_UPFOLD) {
-        // effective tap k4 sums parameter taps: 0:{2} 1:{1,2} 2:{0,1} 3:{0}
-        const int k4y = t >> 2, k4x = t & 3;
-        const int ylo = k4y == 0 ? 2 : (k4y == 1 ? 1 : 0), yhi = k4y == 0 ? 2 : (k4y == 1 ? 2 : (k4y == 2 ? 1 : 0));
-        const int xlo = k4x == 0 ? 2 : (k4x == 1 ? 1 : 0), xhi = k4x == 0 ? 2 : (k4x == 1 ? 2 : (k4x == 2 ? 1 : 0));
-        for (int ky = ylo; ky <= yhi; ++ky)
-          for (int kx = xlo; kx <= xhi; ++kx) v += wp[ky * 3 + kx];
-      } else {
-        v = wp[t];
-      }
+    if (mode == S2I_PACK_UPFOLD) {
+      // effective tap k4 sums parameter taps: 0:{2} 1:{1,2} 2:{0,1} 3:{0}
+      const int k4y = t >> 2, k4x = t & 3;
+      const int ylo = k4y == 0 ? 2 : (k4y == 1 ? 1 : 0), yhi = k4y == 0 ? 2 : (k4y == 1 ? 2 : (k4y == 2 ? 1 : 0));
+      const int xlo = k4x == 0 ? 2 : (k4x == 1 ? 1 : 0), xhi = k4x == 0 ? 2 : (k4x == 1 ? 2 : (k4x == 2 ? 1 : 0));
+      for (int ky = ylo; ky <= yhi; ++ky)
+        for (int kx = xlo; kx <= xhi; ++kx) v += tp[ky * 3 + kx];
+    } else {
+      v = tp[t];
     }
-    packed[e] = v;
+    packed[((size_t)t * Ip + i) * Op + o] = v;
   }
 }
 
@@ -575,7 +611,7 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   const long long tiles = (long long)pl->gridK * pl->gridN;
   int splitk = (int)((1024 + tiles - 1) / tiles);
   if (splitk > pl->nchunks / 4) splitk = pl->nchunks / 4;
-  if (splitk > 1024) splitk = 1024;
+  if (splitk > 256) splitk = 256;
   if (splitk < 1) splitk = 1;
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
@@ -676,11 +712,15 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
   S2I_LAUNCH_CHECK("igemm_wgrad");
-  const long long total = (long long)d->O * d->I * d->KH * d->KW;
-  int blocks = s2i_cdiv(total, 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_finish_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, pl.splitk, pl.K,
-                     d->N, pl.Cin, d->O, d->I, d->KH, d->KW, d->swap, d->fold, d->accumulate, grad_oihw);
+  {
+    const int ncols = d->swap ? d->I : d->O, nrows = d->swap ? d->O : d->I;
+    int RT = 8;
+    while (RT > 1 && (long long)s2i_cdiv(ncols, 32) * s2i_cdiv(nrows, RT) < 128) RT >>= 1;
+    dim3 fgrid(s2i_cdiv(ncols, 32), s2i_cdiv(nrows, RT));
+    const size_t shb = (size_t)pl.T * RT * 33 * sizeof(float);
+    hipLaunchKernelGGL(wgrad_finish_kernel, fgrid, dim3(256), shb, st, (const float*)ws, pl.splitk, pl.K, d->N,
+                       pl.Cin, d->O, d->I, d->KH * d->KW, pl.T, d->swap, d->fold, d->accumulate, RT, grad_oihw);
+  }
   S2I_LAUNCH_CHECK("wgrad_finish");
   return 0;
 }
@@ -697,11 +737,12 @@ extern "C" int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, i
     S2I_REQUIRE(mode == S2I_PACK_PLAIN, "pack: unknown mode %d", mode);
   }
   const int Op = (O + 3) & ~3;
-  const long long total = (long long)T * Ip * Op;
-  int blocks = s2i_cdiv(total, 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, O, I,
-                     KH, KW, Ip, Op, T, mode);
+  {
+    dim3 pgrid(s2i_cdiv(Op, 32), s2i_cdiv(Ip, 8));
+    const size_t shb = (size_t)32 * (8 * KH * KW + 1) * sizeof(float);
+    hipLaunchKernelGGL(pack_weight_kernel, pgrid, dim3(256), shb, (hipStream_t)stream, w_oihw, packed, O, I, KH * KW,
+                       Ip, Op, T, mode);
+  }
   S2I_LAUNCH_CHECK("pack_weight");
   return 0;
 }

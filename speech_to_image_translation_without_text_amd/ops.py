@@ -26,6 +26,15 @@ from ._lib import (ACT_GLU, ACT_LRELU, ACT_NONE, ACT_TANH, CONV_K1, CONV_K3S1, C
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# When True (set by the fused trainer), parameter gradients are accumulated by the kernels straight into
+# `param.grad` (the flat gradient buffer's views) and backward returns None for them: no temporary
+# gradient tensors, no autograd AccumulateGrad add kernels.  Requires zeroed, pre-attached `.grad`.
+DIRECT_PARAM_GRAD = False
+
+
+def _direct(p):
+    return DIRECT_PARAM_GRAD and p is not None and p.grad is not None and p.grad.is_contiguous()
+
 
 def _lib_ready():
     lib = _lib.load()
@@ -207,10 +216,14 @@ def _dgrad(kind_name, dy, w, packed, n_in):
     return y
 
 
-def _wgrad(kind_name, x, cvec, dy, w_shape):
+def _wgrad(kind_name, x, cvec, dy, weight):
+    """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode."""
+    out, acc = (weight.grad, True) if _direct(weight) else (None, False)
     if kind_name == "up":
-        return wgrad_raw(CONV_K4S2, dy, None, x, tuple(w_shape), swap=1, fold=1)
-    return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(w_shape))
+        dw = wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
+    else:
+        dw = wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
+    return None if acc else dw
 
 
 def _split_input_grad(dx_full, Cc):
@@ -259,6 +272,7 @@ class ConvBnAct(torch.autograd.Function):
         check(lib.s2i_bn_act_forward(ptr(y), M, Cout, ptr(coef), act, ptr(residual), ptr(out), stream()),
               "s2i_bn_act_forward")
         ctx.save_for_backward(x, cvec, weight, gamma, y, coef)
+        ctx.beta_ref = beta
         ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
         return out
 
@@ -275,11 +289,15 @@ class ConvBnAct(torch.autograd.Function):
         part = torch.empty((2, nparts, Cout), dtype=torch.float32, device=y.device)
         check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ctx.act, ptr(part), nparts,
                                         stream()), "s2i_bn_act_bwd_reduce")
-        dgamma = torch.empty_like(gamma)
-        dbeta = torch.empty_like(gamma)
+        beta = ctx.beta_ref
+        direct_bn = _direct(gamma) and _direct(beta)
+        dgamma = gamma.grad if direct_bn else torch.empty_like(gamma)
+        dbeta = beta.grad if direct_bn else torch.empty_like(gamma)
         red2 = torch.empty((2, Cout), dtype=torch.float32, device=y.device)
-        check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, Cout, M, ptr(dgamma), ptr(dbeta), 0, ptr(red2), stream()),
-              "s2i_bn_bwd_finalize")
+        check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, Cout, M, ptr(dgamma), ptr(dbeta), 1 if direct_bn else 0,
+                                      ptr(red2), stream()), "s2i_bn_bwd_finalize")
+        if direct_bn:
+            dgamma = dbeta = None
         dy = torch.empty_like(y)
         check(lib.s2i_bn_act_bwd_apply(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ptr(red2), ctx.act, ptr(dy),
                                        stream()), "s2i_bn_act_bwd_apply")
@@ -293,7 +311,7 @@ class ConvBnAct(torch.autograd.Function):
             if not need_x:
                 dx = None
         if need_w:
-            dw = _wgrad(ctx.kind_name, x, cvec, dy, weight.shape)
+            dw = _wgrad(ctx.kind_name, x, cvec, dy, weight)
         dres = dout if ctx.has_res else None
         return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None
 
@@ -329,7 +347,7 @@ class ConvAct(torch.autograd.Function):
             packed = packed_weight(weight, PACK_PLAIN)
             dx = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1])
         if ctx.needs_input_grad[1]:
-            dw = _wgrad(ctx.kind_name, x, None, dy, weight.shape)
+            dw = _wgrad(ctx.kind_name, x, None, dy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             part = torch.empty((2, 1, N), dtype=torch.float32, device=dy.device)
             check(lib.s2i_colstats(ptr(dy), M, N, N, ptr(part), 1, stream()), "s2i_colstats")
@@ -429,6 +447,7 @@ class LogitHead(torch.autograd.Function):
               "s2i_logit_forward")
         ctx.save_for_backward(x, weight, prob)
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         return prob
 
     @staticmethod
@@ -437,10 +456,19 @@ class LogitHead(torch.autograd.Function):
         x, weight, prob = ctx.saved_tensors
         B, _, _, C = x.shape
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(weight) if ctx.needs_input_grad[1] else None
-        db = torch.empty((1,), dtype=torch.float32, device=x.device) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        bias = ctx.bias_ref
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        direct = want_w and _direct(weight) and (not want_b or _direct(bias))
+        if direct:
+            dw, db = weight.grad, (bias.grad if want_b else None)
+        else:
+            dw = torch.empty_like(weight) if want_w else None
+            db = torch.empty((1,), dtype=torch.float32, device=x.device) if want_b else None
         check(lib.s2i_logit_backward(ptr(x), ptr(weight.contiguous()), ptr(prob), ptr(dprob.contiguous()), B, C,
-                                     ptr(dx), 0, ptr(dw), ptr(db), 0, stream()), "s2i_logit_backward")
+                                     ptr(dx), 0, ptr(dw), ptr(db), 1 if direct else 0, stream()), "s2i_logit_backward")
+        if direct:
+            dw = db = None
         return dx, dw, db
 
 

@@ -334,6 +334,7 @@ class condGANTrainer(object):
 
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
+        ops.DIRECT_PARAM_GRAD = True  # kernels accumulate into the flat gradient buffers (zeroed per update)
         self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
