@@ -34,6 +34,7 @@ struct IgemmP {
   int M, N, K, T;
   int kind, flip, act, stats, splitk, cps, nchunks;
   int ldw, wR, ldy, nparts;
+  unsigned x_bytes, c_bytes, w_bytes;
   long long Mrows;
 };
 
@@ -85,8 +86,17 @@ __device__ __forceinline__ void mma_chunk(const float* As, const float* Bs, int 
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT>
-__global__ __launch_bounds__(256) void igemm_fwd_kernel(IgemmP p) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define S2I_OOB 0x7ffffff0  // byte offset past any tensor: the buffer bounds check returns zeros
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// CA32: gathered channel count (and the broadcast-vector part of it) is a multiple of 32, so a 32-deep K
+// chunk lies inside ONE tap (and entirely in x or entirely in cvec): the tap decode is scalar work.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT, bool CA32>
+__global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM + 1;
   constexpr int LDB = WT ? BN + 1 : BN;
@@ -107,15 +117,20 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(IgemmP p) {
   int s, pad, kw;
   geom(p.kind, s, pad, kw);
 
-  long long abase[ASLOTS];
+  // hardware-bounds-checked descriptors: an invalid element is fetched at S2I_OOB and reads as zero,
+  // so the gather needs no exec-mask branches
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.cvec, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  int aoff[ASLOTS];     // byte offset of the slot's base pixel (may be negative; only used when in bounds)
   unsigned amask[ASLOTS];
-  int acoff[ASLOTS];
+  int acoff[ASLOTS];    // byte offset of the slot's row of cvec
 #pragma unroll
   for (int i = 0; i < ASLOTS; ++i) {
     const int m = m0 + mrow + 32 * i;
     unsigned mask = 0;
-    long long base = 0;
-    int coff = 0;
+    int base = 0, coff = 0;
     if (m < p.M) {
       const int b = m >> p.lgHoWo;
       const int r = m & ((1 << p.lgHoWo) - 1);
@@ -127,63 +142,88 @@ __global__ __launch_bounds__(256) void igemm_fwd_kernel(IgemmP p) {
         const int iy = by + dy, ix = bx + dx;
         if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
       }
-      base = (((long long)b * p.H + by) * p.W + bx) * p.Cx;
-      coff = b * p.Cc;
+      base = (((b * p.H + by) * p.W + bx) * p.Cx + kq * 4) * 4;
+      coff = (b * p.Cc + kq * 4) * 4;
     }
-    abase[i] = base;
+    aoff[i] = base;
     amask[i] = mask;
     acoff[i] = coff;
   }
-  // direct-mode B mapping
+  // per-thread constant parts of the weight addresses
   const int bcol4 = tid % (BN / 4), brow = tid / (BN / 4);
+  int wconst[BSLOTS];
+#pragma unroll
+  for (int j = 0; j < BSLOTS; ++j) {
+    if (WT) {
+      const int n = n0 + mrow + 32 * j;
+      wconst[j] = n < p.N ? (n * p.ldw + kq * 4) * 4 : S2I_OOB;
+    } else {
+      const int n = n0 + bcol4 * 4;
+      wconst[j] = n < p.ldw ? ((brow + j * BROWS_PER_PASS) * p.ldw + n) * 4 : S2I_OOB;
+    }
+  }
 
   f32x4 ra[ASLOTS], rb[BSLOTS];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
   auto fetch = [&](int kc) {
-    const int k = kc * 32 + kq * 4;
-    int t = 0, c = 0, tw = 0;
-    long long toff = 0;
-    const bool kvalid = k < p.K;
-    if (kvalid) {
-      t = k / p.Ca;
-      c = k - t * p.Ca;
+    if (CA32) {
+      // wave-uniform tap decode
+      const int k0 = kc * 32;
+      const int t = k0 / p.Ca;
+      const int c0 = k0 - t * p.Ca;
       int dy, dx;
       tap_delta(p.kind, kw, t, py, px, dy, dx);
-      toff = ((long long)dy * p.W + dx) * p.Cx + (c - p.Cc);
-      tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
-    }
+      const int tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+      if (c0 < p.Cc) {
 #pragma unroll
-    for (int i = 0; i < ASLOTS; ++i) {
-      f32x4 v = zero4;
-      if (kvalid && ((amask[i] >> t) & 1u)) {
-        if (c < p.Cc) v = *reinterpret_cast<const f32x4*>(p.cvec + acoff[i] + c);
-        else v = *reinterpret_cast<const f32x4*>(p.x + abase[i] + toff);
-      }
-      ra[i] = v;
-    }
-    if (WT) {
+        for (int i = 0; i < ASLOTS; ++i)
+          ra[i] = bload4(rc, ((amask[i] >> t) & 1u) ? acoff[i] + c0 * 4 : S2I_OOB);
+      } else {
+        const int toff = ((dy * p.W + dx) * p.Cx + (c0 - p.Cc)) * 4;
 #pragma unroll
-      for (int j = 0; j < BSLOTS; ++j) {
-        const int n = n0 + mrow + 32 * j;
-        f32x4 v = zero4;
-        if (kvalid && n < p.N)
-          v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)tw * p.wR + n) * p.ldw + c);
-        rb[j] = v;
+        for (int i = 0; i < ASLOTS; ++i)
+          ra[i] = bload4(rx, ((amask[i] >> t) & 1u) ? aoff[i] + toff : S2I_OOB);
       }
+      const int wbase = WT ? (tw * p.wR * p.ldw + c0) * 4 : (tw * p.wR + c0) * p.ldw * 4;
+#pragma unroll
+      for (int j = 0; j < BSLOTS; ++j) rb[j] = bload4(rw, wconst[j] == S2I_OOB ? S2I_OOB : wbase + wconst[j]);
     } else {
+      const int k = kc * 32 + kq * 4;
+      const bool kvalid = k < p.K;
+      int t = 0, c = 0, tw = 0, toff = 0;
+      if (kvalid) {
+        t = k / p.Ca;
+        c = k - t * p.Ca;
+        int dy, dx;
+        tap_delta(p.kind, kw, t, py, px, dy, dx);
+        toff = ((dy * p.W + dx) * p.Cx + (c - kq * 4 - p.Cc)) * 4;
+        tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+      }
+      const bool from_vec = c < p.Cc;
 #pragma unroll
-      for (int q = 0; q < BSLOTS; ++q) {
-        const int kb = kc * 32 + brow + q * BROWS_PER_PASS;
-        const int n = n0 + bcol4 * 4;
-        f32x4 v = zero4;
-        if (kb < p.K && n < p.ldw) {
-          const int tb = kb / p.Ca;
-          const int cb = kb - tb * p.Ca;
-          const int twb = tap_weight(p.kind, p.flip, p.T, tb, py, px);
-          v = *reinterpret_cast<const f32x4*>(p.w + ((size_t)twb * p.wR + cb) * p.ldw + n);
+      for (int i = 0; i < ASLOTS; ++i) {
+        const bool ok = kvalid && ((amask[i] >> t) & 1u);
+        f32x4 vx = bload4(rx, (ok && !from_vec) ? aoff[i] + toff : S2I_OOB);
+        if (p.Cc > 0) vx += bload4(rc, (ok && from_vec) ? acoff[i] + (c - kq * 4) * 4 : S2I_OOB);
+        ra[i] = vx;
+      }
+      if (WT) {
+#pragma unroll
+        for (int j = 0; j < BSLOTS; ++j)
+          rb[j] = bload4(rw, (kvalid && wconst[j] != S2I_OOB) ? (tw * p.wR * p.ldw + c - kq * 4) * 4 + wconst[j] : S2I_OOB);
+      } else {
+#pragma unroll
+        for (int q = 0; q < BSLOTS; ++q) {
+          const int kb = kc * 32 + brow + q * BROWS_PER_PASS;
+          int off = S2I_OOB;
+          if (kb < p.K && wconst[q] != S2I_OOB) {
+            const int tb = kb / p.Ca;
+            const int cb = kb - tb * p.Ca;
+            const int twb = tap_weight(p.kind, p.flip, p.T, tb, py, px);
+            off = ((twb * p.wR + cb) * p.ldw + n0 + bcol4 * 4) * 4;
+          }
+          rb[q] = bload4(rw, off);
         }
-        rb[q] = v;
       }
     }
   };
@@ -328,7 +368,7 @@ struct WgradP {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM, LDB = BN;
   constexpr int APASS = BM / 32, BPASS = BN / 32;
@@ -426,6 +466,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(WgradP p) {
         if (n < p.N) outp[(size_t)krow * p.N + n] = acc[i][j][r];
       }
     }
+}
+
+// slab[0] += slab[1..S-1]: a pure float4 stream over the split slabs (full-chip parallel, HBM-bound)
+__global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ slab, int S, long long n4) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4;
+       e += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(slab + e * 4);
+    for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(slab + ((size_t)s * n4 + e) * 4);
+    *reinterpret_cast<f32x4*>(slab + e * 4) = v;
+  }
 }
 
 // Reduce the split slabs and write the reference's OIHW gradient tensor.  A [T][RT][32] tile goes through
@@ -609,7 +659,7 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   pl->gridN = s2i_cdiv(d->N, BN);
   pl->nchunks = s2i_cdiv(M, 32);
   const long long tiles = (long long)pl->gridK * pl->gridN;
-  int splitk = (int)((1024 + tiles - 1) / tiles);
+  int splitk = (int)((512 + tiles - 1) / tiles);
   if (splitk > pl->nchunks / 4) splitk = pl->nchunks / 4;
   if (splitk > 256) splitk = 256;
   if (splitk < 1) splitk = 1;
@@ -619,9 +669,14 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
 }
 
 template <int BM, int BN, int WM, int WN>
-void launch_fwd(const IgemmP& p, dim3 grid, bool wt, hipStream_t st) {
-  if (wt) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, p);
+void launch_fwd(const IgemmP& p, dim3 grid, bool wt, bool ca32, hipStream_t st) {
+  if (wt) {
+    if (ca32) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (ca32) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, p);
+  }
 }
 
 }  // namespace
@@ -670,9 +725,17 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
   p.Mrows = pl.Mrows;
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   const bool wt = d->wmode != 0;
-  if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, st);
-  else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, st);
-  else launch_fwd<128, 32, 4, 1>(p, grid, wt, st);
+  const int wtaps = d->kind == S2I_TCONV_K4S2 ? 16 : pl.T;
+  const unsigned long long xb = (unsigned long long)d->B * d->H * d->W * d->Cx * 4ull;
+  const unsigned long long wb = (unsigned long long)wtaps * d->wR * d->ldw * 4ull;
+  S2I_REQUIRE(xb < 0x7ff00000ull && wb < 0x7ff00000ull, "conv: tensor exceeds the 2 GiB buffer-addressing window");
+  p.x_bytes = (unsigned)xb;
+  p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
+  p.w_bytes = (unsigned)wb;
+  const bool ca32 = (pl.Ca % 32) == 0 && (d->Cc % 32) == 0;
+  if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, ca32, st);
+  else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, ca32, st);
+  else launch_fwd<128, 32, 4, 1>(p, grid, wt, ca32, st);
   S2I_LAUNCH_CHECK("igemm_fwd");
   if (pl.splitk > 1) {
     const long long total = pl.Mrows * d->N;
@@ -718,7 +781,16 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     while (RT > 1 && (long long)s2i_cdiv(ncols, 32) * s2i_cdiv(nrows, RT) < 128) RT >>= 1;
     dim3 fgrid(s2i_cdiv(ncols, 32), s2i_cdiv(nrows, RT));
     const size_t shb = (size_t)pl.T * RT * 33 * sizeof(float);
-    hipLaunchKernelGGL(wgrad_finish_kernel, fgrid, dim3(256), shb, st, (const float*)ws, pl.splitk, pl.K, d->N,
+    int S = pl.splitk;
+    const long long kn = (long long)pl.K * d->N;
+    if (S > 2 && (kn % 4) == 0) {
+      int sb = s2i_cdiv(kn / 4, 256);
+      if (sb > 4096) sb = 4096;
+      hipLaunchKernelGGL(slab_sum_kernel, dim3(sb), dim3(256), 0, st, (float*)ws, S, kn / 4);
+      S2I_LAUNCH_CHECK("slab_sum");
+      S = 1;
+    }
+    hipLaunchKernelGGL(wgrad_finish_kernel, fgrid, dim3(256), shb, st, (const float*)ws, S, pl.K, d->N,
                        pl.Cin, d->O, d->I, d->KH * d->KW, pl.T, d->swap, d->fold, d->accumulate, RT, grad_oihw);
   }
   S2I_LAUNCH_CHECK("wgrad_finish");

@@ -1,0 +1,44 @@
+"""Micro-benchmark of representative implicit-GEMM launches (dev tool, GPU box only)."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speech_to_image_translation_without_text_amd import ops  # noqa: E402
+from speech_to_image_translation_without_text_amd._lib import CONV_K3S1, CONV_K4S2, TCONV_K4S2  # noqa: E402
+
+dev = torch.device("cuda:0")
+B = 24
+CASES = [
+    # name, kind, x shape, N, wmode, packed shape, flops
+    ("fwd k4s2 64->128 @128", CONV_K4S2, (B, 128, 128, 64), 128, 0, (16, 64, 128)),
+    ("fwd k4s2 512->1024 @16", CONV_K4S2, (B, 16, 16, 512), 1024, 0, (16, 512, 1024)),
+    ("dgr tconv 256<-512 @16", TCONV_K4S2, (B, 16, 16, 512), 256, 1, (16, 256, 512)),
+    ("fwd k3s1 64->128 @64", CONV_K3S1, (B, 64, 64, 64), 128, 0, (9, 64, 128)),
+    ("dgr k3s1 64<-128 @64", CONV_K3S1, (B, 64, 64, 128), 64, 1, (9, 64, 128)),
+    ("fwd up 64->64 @64->128", TCONV_K4S2, (B, 64, 64, 64), 64, 0, (16, 64, 64)),
+]
+which = sys.argv[1:] or None
+reps = int(os.environ.get("REPS", "20"))
+for name, kind, xs, N, wmode, ps in CASES:
+    if which and not any(w in name for w in which):
+        continue
+    x = torch.randn(xs, device=dev)
+    packed = torch.randn(ps, device=dev) * 0.05
+    T = {CONV_K3S1: 9, CONV_K4S2: 16, TCONV_K4S2: 4}[kind]
+    Bx, H, W, Cx = xs
+    Mout = Bx * H * W * (4 if kind == TCONV_K4S2 else 1) // (4 if kind == CONV_K4S2 else 1)
+    flops = 2.0 * Mout * N * T * Cx
+    fn = lambda: ops.conv_raw(kind, x, None, packed, N, wmode=wmode, flip=0, wR=ps[1], ldw=ps[2], stats=(wmode == 0))
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("%-26s %7.3f ms  %6.1f TF" % (name, ms, flops / ms / 1e9))
