@@ -115,7 +115,8 @@ int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int K
  * out4 = [mean | invstd | scale | shift], each C floats.
  */
 int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
-                    const float* beta, float* running_mean, float* running_var, float momentum,
+                    const float* beta, float* running_mean, float* running_var,
+                    long long* num_batches_tracked /* int64, += 1; may be NULL */, float momentum,
                     float eps, float* out4, void* stream);
 /* eval-mode BatchNorm: scale/shift from the running statistics (trainer.py:681-803 path) */
 int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,

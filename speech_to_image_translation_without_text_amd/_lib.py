@@ -42,7 +42,7 @@ _SIGNATURES = {
     "s2i_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "s2i_conv_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P, c_size_t, P]),
     "s2i_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "s2i_bn_finalize": (c_int, [P, c_int, c_int, c_ll, P, P, P, P, c_float, c_float, P, P]),
+    "s2i_bn_finalize": (c_int, [P, c_int, c_int, c_ll, P, P, P, P, P, c_float, c_float, P, P]),
     "s2i_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P]),
     "s2i_bn_act_forward": (c_int, [P, c_ll, c_int, P, c_int, P, P, P]),
     "s2i_colstats": (c_int, [P, c_ll, c_int, c_int, P, c_int, P]),

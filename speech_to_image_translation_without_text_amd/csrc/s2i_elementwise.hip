@@ -113,8 +113,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
                                                            float* __restrict__ out, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, int qpb) {
+                                                           float* __restrict__ dbeta, int accumulate, int qpb,
+                                                           long long* __restrict__ nbt) {
   extern __shared__ double shd[];  // [2][1024][4]
+  if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;  // num_batches_tracked
   const int tid = threadIdx.x;
   const int lanes = 1024 / qpb;
   const int ql = tid % qpb, pl = tid / qpb;
@@ -605,7 +607,7 @@ extern "C" int s2i_colstats(const float* y, long long M, int C, int ldy, float* 
 
 static int launch_finalize(int mode, const float* part, int nparts, int C, long long count, const float* gamma,
                            const float* beta, float* rmean, float* rvar, float momentum, float eps, float* out,
-                           float* dgamma, float* dbeta, int accumulate, void* stream) {
+                           float* dgamma, float* dbeta, int accumulate, void* stream, long long* nbt = nullptr) {
   S2I_REQUIRE(part && out && nparts > 0 && C > 0 && C % 4 == 0 && count > 0, "bn finalize: bad args");
   const int Q = C / 4;
   int qpb = 1;
@@ -614,21 +616,21 @@ static int launch_finalize(int mode, const float* part, int nparts, int C, long 
   const size_t shbytes = 2 * 1024 * 4 * sizeof(double);
   if (mode == 0)
     hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
-                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb);
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   else
     hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
-                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb);
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   S2I_LAUNCH_CHECK("bn_finalize");
   return 0;
 }
 
 extern "C" int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
-                               const float* beta, float* running_mean, float* running_var, float momentum,
-                               float eps, float* out4, void* stream) {
+                               const float* beta, float* running_mean, float* running_var,
+                               long long* num_batches_tracked, float momentum, float eps, float* out4, void* stream) {
   S2I_REQUIRE(gamma && beta, "bn_finalize: null affine parameters");
   S2I_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
   return launch_finalize(0, part, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, out4,
-                         nullptr, nullptr, 0, stream);
+                         nullptr, nullptr, 0, stream, num_batches_tracked);
 }
 
 extern "C" int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,

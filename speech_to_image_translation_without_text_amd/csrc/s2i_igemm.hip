@@ -354,6 +354,45 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long
   }
 }
 
+// split-K reduction fused with the BatchNorm column statistics: y = sum_s slab[s], part = per-row-chunk column
+// sums and sums of squares (the layout s2i_colstats writes).  256 threads = cpb column quads x 256/cpb row lanes.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slab, int S, long long rows,
+                                                                  int N, float* __restrict__ y, int ldy,
+                                                                  float* __restrict__ part, int nparts, int cpb) {
+  __shared__ f32x4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.y * cpb + ql;
+  const int Q = N / 4;
+  const long long chunk = (rows + nparts - 1) / nparts;
+  const long long r0 = (long long)blockIdx.x * chunk;
+  const long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  const size_t sstride = (size_t)rows * N;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (quad < Q) {
+    for (long long row = r0 + rl; row < r1; row += rpb) {
+      const float* sp = slab + row * N + quad * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(sp + s * sstride);
+      *reinterpret_cast<f32x4*>(y + row * ldy + quad * 4) = v;
+      s0 += v;
+      s1 += v * v;
+    }
+  }
+  sh[0][tid] = s0;
+  sh[1][tid] = s1;
+  __syncthreads();
+  if (rl == 0 && quad < Q) {
+    for (int r = 1; r < rpb; ++r) {
+      s0 += sh[0][r * cpb + ql];
+      s1 += sh[1][r * cpb + ql];
+    }
+    *reinterpret_cast<f32x4*>(part + ((size_t)0 * nparts + blockIdx.x) * N + quad * 4) = s0;
+    *reinterpret_cast<f32x4*>(part + ((size_t)1 * nparts + blockIdx.x) * N + quad * 4) = s1;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient: slab[split][krow][n] = sum_{pixels in split} A(pixel, krow) * g[pixel][n]
 struct WgradP {
@@ -365,6 +404,7 @@ struct WgradP {
   int Ho, Wo, lgWo, lgHoWo;
   int M, N, ldg, K, T, kind;
   int cps, nchunks;
+  unsigned a_bytes, c_bytes, g_bytes;
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -398,33 +438,29 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
   const int nb = n0 + bcol4 * 4;
   const bool nvalid = nb < p.N;
 
+  const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.cvec, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  const int acolb = (c - p.Cc) * 4;            // byte offset of this thread's 4 channels inside a pixel of a
+  const int ccolb = c * 4;                     // ... inside a row of cvec
+  const int gcolb = nvalid ? nb * 4 : S2I_OOB;
   f32x4 ra[APASS], rb[BPASS];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int pc) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
       const int m = pc * 32 + arow + q * AROWS;
-      f32x4 v = zero4;
-      if (kvalid && m < p.M) {
-        const int b = m >> p.lgHoWo;
-        const int r = m & ((1 << p.lgHoWo) - 1);
-        const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
-        const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-          if (from_vec) v = *reinterpret_cast<const f32x4*>(p.cvec + b * p.Cc + c);
-          else
-            v = *reinterpret_cast<const f32x4*>(p.a + (((long long)b * p.H + iy) * p.W + ix) * p.Ca +
-                                                (c - p.Cc));
-        }
-      }
-      ra[q] = v;
+      const int b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+      const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+      const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      if (from_vec) ra[q] = bload4(rc_rs, ok ? b * p.Cc * 4 + ccolb : S2I_OOB);
+      else ra[q] = bload4(ra_rs, ok ? ((b * p.H + iy) * p.W + ix) * p.Ca * 4 + acolb : S2I_OOB);
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int m = pc * 32 + brow + q * BROWS;
-      f32x4 v = zero4;
-      if (nvalid && m < p.M) v = *reinterpret_cast<const f32x4*>(p.g + (long long)m * p.ldg + nb);
-      rb[q] = v;
+      rb[q] = bload4(rg_rs, (m < p.M && nvalid) ? m * p.ldg * 4 + gcolb : S2I_OOB);
     }
   };
 
@@ -615,8 +651,9 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   pl->nchunks = s2i_cdiv(pl->K, 32);
   const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
   int splitk = 1;
-  if (blocks < 256 && pl->nchunks >= 16) {
-    splitk = (int)((768 + blocks - 1) / blocks);
+  if (blocks < 512 && pl->nchunks >= 16) {
+    // three 256-thread blocks fit per CU: split K until about 768 blocks exist
+    splitk = (int)(768 / blocks);
     if (splitk > pl->nchunks / 8) splitk = pl->nchunks / 8;
     if (splitk > 64) splitk = 64;
     if (splitk < 1) splitk = 1;
@@ -690,8 +727,8 @@ extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
 // number of rows the stats pass writes; split-K layers take the column-stats kernel instead
 static int stat_parts_for(const FwdPlan& pl) {
   if (pl.splitk > 1) {
-    int np = s2i_cdiv(pl.Mrows, 64);
-    return np > 256 ? 256 : np;
+    int np = s2i_cdiv(pl.Mrows, 8);  // split-K layers have few rows: keep the reduce+stats pass wide
+    return np > 512 ? 512 : np;
   }
   return pl.gridM * pl.nphases;
 }
@@ -738,6 +775,16 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
   else launch_fwd<128, 32, 4, 1>(p, grid, wt, ca32, st);
   S2I_LAUNCH_CHECK("igemm_fwd");
   if (pl.splitk > 1) {
+    if (d->stats && (d->N % 4) == 0 && (d->ldy % 4) == 0) {
+      const int Q = d->N / 4;
+      int cpb = 1;
+      while (cpb < Q && cpb < 256) cpb <<= 1;
+      const int nparts = stat_parts_for(pl);
+      hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(nparts, (Q + cpb - 1) / cpb), dim3(256), 0, st,
+                         (const float*)ws, pl.splitk, pl.Mrows, d->N, y, d->ldy, part, nparts, cpb);
+      S2I_LAUNCH_CHECK("splitk_reduce_stats");
+      return 0;
+    }
     const long long total = pl.Mrows * d->N;
     int blocks = s2i_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
@@ -770,6 +817,13 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
   p.Ho = pl.Ho; p.Wo = pl.Wo; p.lgWo = s2i_ilog2(pl.Wo); p.lgHoWo = s2i_ilog2(pl.Ho * pl.Wo);
   p.M = pl.M; p.N = d->N; p.ldg = d->ldg; p.K = pl.K; p.T = pl.T; p.kind = d->kind;
   p.cps = pl.cps; p.nchunks = pl.nchunks;
+  {
+    const unsigned long long ab = (unsigned long long)d->B * d->H * d->W * d->Ca * 4ull;
+    const unsigned long long gb = (unsigned long long)pl.M * d->ldg * 4ull;
+    S2I_REQUIRE(ab < 0x7ff00000ull && gb < 0x7ff00000ull, "wgrad: tensor exceeds the 2 GiB buffer-addressing window");
+    p.a_bytes = (unsigned)ab; p.g_bytes = (unsigned)gb;
+    p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
+  }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
   if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);

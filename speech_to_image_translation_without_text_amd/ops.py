@@ -258,10 +258,8 @@ class ConvBnAct(torch.autograd.Function):
         coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
         rm, rv, nbt = bn_buffers
         if training:
-            check(lib.s2i_bn_finalize(ptr(part), nparts, Cout, M, ptr(gamma), ptr(beta), ptr(rm), ptr(rv),
+            check(lib.s2i_bn_finalize(ptr(part), nparts, Cout, M, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt),
                                       BN_MOMENTUM, BN_EPS, ptr(coef), stream()), "s2i_bn_finalize")
-            if nbt is not None:
-                nbt.add_(1)
         else:
             check(lib.s2i_bn_eval_coeffs(Cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, ptr(coef), stream()),
                   "s2i_bn_eval_coeffs")
