@@ -65,6 +65,9 @@ typedef struct s2i_conv_desc {
   int act;       /* epilogue: S2I_ACT_NONE / LRELU / TANH                                        */
   int stats;     /* 1: also emit per-row-tile column sums and sums of squares (BatchNorm)       */
   int ldy;       /* row stride of y                                                             */
+  int groups;    /* BatchNorm groups: the rows are `groups` equal, independent batches stacked along
+                    the batch axis (real / wrong / fake passes of trainer.py:390-392 in one launch);
+                    statistics are kept per group.  0 or 1 = one batch                           */
 } s2i_conv_desc;
 
 /* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */
@@ -112,9 +115,11 @@ int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int K
  * Reduce the conv epilogue's partials to batch statistics (nn.BatchNorm2d/1d in training mode,
  * model.py:137, 147, 158, 161, 218, 361, 372): mean, biased var -> invstd, scale = gamma*invstd,
  * shift = beta - mean*scale; running_mean/var updated with momentum (unbiased var), as torch does.
- * out4 = [mean | invstd | scale | shift], each C floats.
+ * out4 = [mean | invstd | scale | shift], each C floats, once per group (groups x 4 x C); `count` is
+ * the number of rows of ONE group; the partial rows are split evenly over the groups, which are
+ * processed in order (running statistics receive `groups` successive updates).
  */
-int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+int s2i_bn_finalize(const float* part, int nparts, int groups, int C, long long count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var,
                     long long* num_batches_tracked /* int64, += 1; may be NULL */, float momentum,
                     float eps, float* out4, void* stream);
@@ -125,7 +130,7 @@ int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float
  * out = act(scale*y + shift) (+ residual).  GLU halves the channel count (C -> C/2).
  * Replaces BatchNorm apply + GLU / LeakyReLU / ResBlock add (model.py:116-122, 165-169).
  */
-int s2i_bn_act_forward(const float* y, long long M, int C, const float* coef4, int act,
+int s2i_bn_act_forward(const float* y, long long M, int groups, int C, const float* coef4, int act,
                        const float* residual, float* out, void* stream);
 /* column sums of the raw tensor when no conv epilogue produced them: part = [2][nparts][C] */
 int s2i_colstats(const float* y, long long M, int C, int ldy, float* part, int nparts,
@@ -134,14 +139,14 @@ int s2i_colstats(const float* y, long long M, int C, int ldy, float* part, int n
  * Backward of bn_act_forward, pass 1: per-channel sums of dz and dz*xhat (dz = gradient w.r.t. the
  * BatchNorm output after un-doing the activation).  part = [2][nparts][C].
  */
-int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int C,
+int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int groups, int C,
                           const float* coef4, int act, float* part, int nparts, void* stream);
 /* finalise pass 1: dgamma, dbeta (accumulated or assigned) and the two means for pass 2.
    red2 = [mean_dz | mean_dz_xhat], each C floats. */
-int s2i_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+int s2i_bn_bwd_finalize(const float* part, int nparts, int groups, int C, long long count, float* dgamma,
                         float* dbeta, int accumulate, float* red2, void* stream);
 /* pass 2: dy = scale * (dz - mean_dz - xhat*mean_dz_xhat) */
-int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int C,
+int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int groups, int C,
                          const float* coef4, const float* red2, int act, float* dy, void* stream);
 
 /* ---- plain activations ---------------------------------------------------------------------- */

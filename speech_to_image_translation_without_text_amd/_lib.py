@@ -23,7 +23,7 @@ c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Cx", "Cc", "N", "wmode", "flip", "wR",
-                                     "ldw", "act", "stats", "ldy")]
+                                     "ldw", "act", "stats", "ldy", "groups")]
 
 
 class WgradDesc(ctypes.Structure):
@@ -42,13 +42,13 @@ _SIGNATURES = {
     "s2i_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "s2i_conv_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P, c_size_t, P]),
     "s2i_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "s2i_bn_finalize": (c_int, [P, c_int, c_int, c_ll, P, P, P, P, P, c_float, c_float, P, P]),
+    "s2i_bn_finalize": (c_int, [P, c_int, c_int, c_int, c_ll, P, P, P, P, P, c_float, c_float, P, P]),
     "s2i_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P]),
-    "s2i_bn_act_forward": (c_int, [P, c_ll, c_int, P, c_int, P, P, P]),
+    "s2i_bn_act_forward": (c_int, [P, c_ll, c_int, c_int, P, c_int, P, P, P]),
     "s2i_colstats": (c_int, [P, c_ll, c_int, c_int, P, c_int, P]),
-    "s2i_bn_act_bwd_reduce": (c_int, [P, P, c_int, c_ll, c_int, P, c_int, P, c_int, P]),
-    "s2i_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_ll, P, P, c_int, P, P]),
-    "s2i_bn_act_bwd_apply": (c_int, [P, P, c_int, c_ll, c_int, P, P, c_int, P, P]),
+    "s2i_bn_act_bwd_reduce": (c_int, [P, P, c_int, c_ll, c_int, c_int, P, c_int, P, c_int, P]),
+    "s2i_bn_bwd_finalize": (c_int, [P, c_int, c_int, c_int, c_ll, P, P, c_int, P, P]),
+    "s2i_bn_act_bwd_apply": (c_int, [P, P, c_int, c_ll, c_int, c_int, P, P, c_int, P, P]),
     "s2i_act_backward": (c_int, [P, P, c_int, c_ll, c_int, c_int, P, P]),
     "s2i_glu_forward": (c_int, [P, c_ll, c_int, P, P]),
     "s2i_glu_backward": (c_int, [P, P, c_ll, c_int, P, P]),

@@ -67,16 +67,22 @@ template <int MODE>  // 0: (y, y^2)   1: (dz, dz*xhat)
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y, int ldy,
                                                         const float* __restrict__ dout, int lddout,
                                                         long long M, int C, const float* __restrict__ coef,
-                                                        int act, float* __restrict__ part, int nparts, int cpb) {
+                                                        int act, float* __restrict__ part, int nparts, int cpb,
+                                                        int ppg, long long Rg) {
+  // rows are split into groups of Rg rows (independent BatchNorm batches); part p covers a row chunk of
+  // group p / ppg and uses that group's coefficients
   __shared__ f32x4 sh[2][256];
   const int tid = threadIdx.x;
   const int rpb = 256 / cpb;
   const int ql = tid % cpb, rl = tid / cpb;
   const int quad = blockIdx.y * cpb + ql;
   const int Q = C / 4;
-  const long long chunk = (M + nparts - 1) / nparts;
-  const long long r0 = (long long)blockIdx.x * chunk;
-  const long long r1 = r0 + chunk < M ? r0 + chunk : M;
+  const int grp = blockIdx.x / ppg, pp = blockIdx.x - grp * ppg;
+  const long long chunk = (Rg + ppg - 1) / ppg;
+  const long long r0 = grp * Rg + pp * chunk;
+  const long long gend = (grp + 1) * Rg < M ? (grp + 1) * Rg : M;
+  const long long r1 = r0 + chunk < gend ? r0 + chunk : gend;
+  coef += (size_t)grp * 4 * C;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (quad < Q) {
     f32x4 mean = {0.f, 0.f, 0.f, 0.f}, invstd = {0.f, 0.f, 0.f, 0.f};
@@ -106,9 +112,11 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict_
   }
 }
 
-// reduce [2][nparts][C] partials in double; 1024 threads: qpb quads x (1024/qpb) part lanes
+// reduce [2][G*ppg][C] partials in double; 1024 threads: qpb quads x (1024/qpb) part lanes.  The G groups
+// (independent BatchNorm batches sharing one set of parameters) are processed in order, so the running
+// statistics see G successive momentum updates exactly as G separate forwards would give.
 template <int MODE>  // 0: BN forward statistics   1: BN backward sums
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int ppg, int G, int C,
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
@@ -116,58 +124,73 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ dbeta, int accumulate, int qpb,
                                                            long long* __restrict__ nbt) {
   extern __shared__ double shd[];  // [2][1024][4]
-  if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += 1;  // num_batches_tracked
+  if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += G;  // num_batches_tracked
   const int tid = threadIdx.x;
   const int lanes = 1024 / qpb;
   const int ql = tid % qpb, pl = tid / qpb;
   const int quad = blockIdx.x * qpb + ql;
   const int Q = C / 4;
-  double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-  if (quad < Q) {
-    for (int pi = pl; pi < nparts; pi += lanes) {
-      const f32x4 v0 = ld4(part + ((size_t)0 * nparts + pi) * C + quad * 4);
-      const f32x4 v1 = ld4(part + ((size_t)1 * nparts + pi) * C + quad * 4);
+  const int nparts = ppg * G;
+  double g0[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0};  // sums over groups (backward: dbeta, dgamma)
+  for (int grp = 0; grp < G; ++grp) {
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    if (quad < Q) {
+      for (int pi = grp * ppg + pl; pi < (grp + 1) * ppg; pi += lanes) {
+        const f32x4 v0 = ld4(part + ((size_t)0 * nparts + pi) * C + quad * 4);
+        const f32x4 v1 = ld4(part + ((size_t)1 * nparts + pi) * C + quad * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a0[j] += v0[j]; a1[j] += v1[j]; }
+        for (int j = 0; j < 4; ++j) { a0[j] += v0[j]; a1[j] += v1[j]; }
+      }
     }
-  }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    shd[(0 * 1024 + tid) * 4 + j] = a0[j];
-    shd[(1 * 1024 + tid) * 4 + j] = a1[j];
-  }
-  __syncthreads();
-  if (pl == 0 && quad < Q) {
-    for (int r = 1; r < lanes; ++r)
+    for (int j = 0; j < 4; ++j) {
+      shd[(0 * 1024 + tid) * 4 + j] = a0[j];
+      shd[(1 * 1024 + tid) * 4 + j] = a1[j];
+    }
+    __syncthreads();
+    if (pl == 0 && quad < Q) {
+      for (int r = 1; r < lanes; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a0[j] += shd[(0 * 1024 + r * qpb + ql) * 4 + j];
+          a1[j] += shd[(1 * 1024 + r * qpb + ql) * 4 + j];
+        }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        a0[j] += shd[(0 * 1024 + r * qpb + ql) * 4 + j];
-        a1[j] += shd[(1 * 1024 + r * qpb + ql) * 4 + j];
+        const int c = quad * 4 + j;
+        if (MODE == 0) {
+          float* o = out + (size_t)grp * 4 * C;
+          const double mean = a0[j] / count;
+          double var = a1[j] / count - mean * mean;
+          if (var < 0) var = 0;
+          const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+          const float sc = gamma[c] * invstd;
+          o[c] = (float)mean;
+          o[C + c] = invstd;
+          o[2 * C + c] = sc;
+          o[3 * C + c] = beta[c] - (float)mean * sc;
+          if (rmean) {
+            const double unb = count > 1 ? var * count / (count - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+          }
+        } else {
+          float* o = out + (size_t)grp * 2 * C;
+          o[c] = (float)(a0[j] / count);
+          o[C + c] = (float)(a1[j] / count);
+          g0[j] += a0[j];
+          g1[j] += a1[j];
+        }
       }
+    }
+  }
+  if (MODE == 1 && pl == 0 && quad < Q) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = quad * 4 + j;
-      if (MODE == 0) {
-        const double mean = a0[j] / count;
-        double var = a1[j] / count - mean * mean;
-        if (var < 0) var = 0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
-        out[c] = (float)mean;
-        out[C + c] = invstd;
-        out[2 * C + c] = sc;
-        out[3 * C + c] = beta[c] - (float)mean * sc;
-        if (rmean) {
-          const double unb = count > 1 ? var * count / (count - 1) : var;
-          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-          rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-        }
-      } else {
-        out[c] = (float)(a0[j] / count);
-        out[C + c] = (float)(a1[j] / count);
-        if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a0[j] : (float)a0[j];
-        if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)a1[j] : (float)a1[j];
-      }
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)g0[j] : (float)g0[j];
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)g1[j] : (float)g1[j];
     }
   }
 }
@@ -186,11 +209,9 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
 }
 
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, long long M, int C,
-                                                         const float* __restrict__ coef, int act,
+                                                         const float* __restrict__ coef0, int act,
                                                          const float* __restrict__ residual,
-                                                         float* __restrict__ out) {
-  const float* scale = coef + 2 * C;
-  const float* shift = coef + 3 * C;
+                                                         float* __restrict__ out, int G, unsigned Rg) {
   const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
   const int Qo = Cout / 4;
   const long long total = M * Qo;
@@ -198,6 +219,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
        e += (long long)gridDim.x * blockDim.x) {
     const long long row = e / Qo;
     const int q = (int)(e - row * Qo);
+    const float* coef = G > 1 ? coef0 + (size_t)((unsigned)row / Rg) * 4 * C : coef0;
+    const float* scale = coef + 2 * C;
+    const float* shift = coef + 3 * C;
     f32x4 o;
     if (act == S2I_ACT_GLU) {
       const f32x4 ya = ld4(y + row * C + q * 4), yg = ld4(y + row * C + Cout + q * 4);
@@ -222,15 +246,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ dout, int lddout,
-                                                               long long M, int C, const float* __restrict__ coef,
-                                                               const float* __restrict__ red2, int act,
-                                                               float* __restrict__ dy) {
+                                                               long long M, int C, const float* __restrict__ coef0,
+                                                               const float* __restrict__ red20, int act,
+                                                               float* __restrict__ dy, int G, unsigned Rg) {
   const int Q = C / 4;
   const long long total = M * Q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
     const long long row = e / Q;
     const int q = (int)(e - row * Q);
+    const unsigned grp = G > 1 ? (unsigned)row / Rg : 0u;
+    const float* coef = coef0 + (size_t)grp * 4 * C;
+    const float* red2 = red20 + (size_t)grp * 2 * C;
     const f32x4 yv = ld4(y + row * C + q * 4);
     const f32x4 dz = act_dz(y, dout, lddout, row, C, q, coef, act, yv);
     const f32x4 mean = ld4(coef + q * 4), invstd = ld4(coef + C + q * 4), sc = ld4(coef + 2 * C + q * 4);
@@ -600,37 +627,41 @@ extern "C" int s2i_colstats(const float* y, long long M, int C, int ldy, float* 
   S2I_REQUIRE(y && part && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && nparts > 0, "colstats: bad args");
   RedGeom g = red_geom(C);
   hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts, g.gy), dim3(256), 0, ST, y, ldy, (const float*)nullptr, 0,
-                     M, C, (const float*)nullptr, 0, part, nparts, g.cpb);
+                     M, C, (const float*)nullptr, 0, part, nparts, g.cpb, nparts, M);
   S2I_LAUNCH_CHECK("colstats");
   return 0;
 }
 
-static int launch_finalize(int mode, const float* part, int nparts, int C, long long count, const float* gamma,
-                           const float* beta, float* rmean, float* rvar, float momentum, float eps, float* out,
-                           float* dgamma, float* dbeta, int accumulate, void* stream, long long* nbt = nullptr) {
+static int launch_finalize(int mode, const float* part, int nparts, int groups, int C, long long count,
+                           const float* gamma, const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                           float* out, float* dgamma, float* dbeta, int accumulate, void* stream,
+                           long long* nbt = nullptr) {
   S2I_REQUIRE(part && out && nparts > 0 && C > 0 && C % 4 == 0 && count > 0, "bn finalize: bad args");
+  S2I_REQUIRE(groups >= 1 && nparts % groups == 0, "bn finalize: %d partial rows do not split into %d groups", nparts,
+              groups);
+  const int ppg = nparts / groups;
   const int Q = C / 4;
   int qpb = 1;
   while (qpb < Q && qpb < 32) qpb <<= 1;
   const int grid = (Q + qpb - 1) / qpb;
   const size_t shbytes = 2 * 1024 * 4 * sizeof(double);
   if (mode == 0)
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(1024), shbytes, ST, part, ppg, groups, C, (double)count,
                        gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   else
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(1024), shbytes, ST, part, nparts, C, (double)count,
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(1024), shbytes, ST, part, ppg, groups, C, (double)count,
                        gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   S2I_LAUNCH_CHECK("bn_finalize");
   return 0;
 }
 
-extern "C" int s2i_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+extern "C" int s2i_bn_finalize(const float* part, int nparts, int groups, int C, long long count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                long long* num_batches_tracked, float momentum, float eps, float* out4, void* stream) {
   S2I_REQUIRE(gamma && beta, "bn_finalize: null affine parameters");
   S2I_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-  return launch_finalize(0, part, nparts, C, count, gamma, beta, running_mean, running_var, momentum, eps, out4,
-                         nullptr, nullptr, 0, stream, num_batches_tracked);
+  return launch_finalize(0, part, nparts, groups, C, count, gamma, beta, running_mean, running_var, momentum, eps,
+                         out4, nullptr, nullptr, 0, stream, num_batches_tracked);
 }
 
 extern "C" int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,
@@ -642,42 +673,46 @@ extern "C" int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
   return 0;
 }
 
-extern "C" int s2i_bn_act_forward(const float* y, long long M, int C, const float* coef4, int act,
+extern "C" int s2i_bn_act_forward(const float* y, long long M, int groups, int C, const float* coef4, int act,
                                   const float* residual, float* out, void* stream) {
   S2I_REQUIRE(y && coef4 && out && M > 0 && C > 0, "bn_act_forward: bad args");
+  S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_forward: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_forward: C=%d not aligned for act %d", C, act);
   S2I_REQUIRE(!(residual && act == S2I_ACT_GLU), "bn_act_forward: residual with GLU unsupported");
   const long long total = M * ((act == S2I_ACT_GLU ? C / 2 : C) / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out,
+                     groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_forward");
   return 0;
 }
 
-extern "C" int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int C,
+extern "C" int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int groups, int C,
                                      const float* coef4, int act, float* part, int nparts, void* stream) {
   S2I_REQUIRE(y && dout && coef4 && part && M > 0 && nparts > 0, "bn_act_bwd_reduce: bad args");
+  S2I_REQUIRE(groups >= 1 && M % groups == 0 && nparts % groups == 0, "bn_act_bwd_reduce: bad grouping");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_reduce: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_reduce: lddout alignment");
   RedGeom g = red_geom(C);
   hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
-                     act, part, nparts, g.cpb);
+                     act, part, nparts, g.cpb, nparts / groups, M / groups);
   S2I_LAUNCH_CHECK("bn_act_bwd_reduce");
   return 0;
 }
 
-extern "C" int s2i_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+extern "C" int s2i_bn_bwd_finalize(const float* part, int nparts, int groups, int C, long long count, float* dgamma,
                                    float* dbeta, int accumulate, float* red2, void* stream) {
-  return launch_finalize(1, part, nparts, C, count, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, red2, dgamma,
+  return launch_finalize(1, part, nparts, groups, C, count, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, red2, dgamma,
                          dbeta, accumulate, stream);
 }
 
-extern "C" int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int C,
+extern "C" int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int groups, int C,
                                     const float* coef4, const float* red2, int act, float* dy, void* stream) {
   S2I_REQUIRE(y && dout && coef4 && red2 && dy && M > 0, "bn_act_bwd_apply: bad args");
+  S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_bwd_apply: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_apply: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_apply: lddout alignment");
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
-                     coef4, red2, act, dy);
+                     coef4, red2, act, dy, groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_bwd_apply");
   return 0;
 }

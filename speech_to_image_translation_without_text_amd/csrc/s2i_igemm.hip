@@ -358,16 +358,19 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long
 // sums and sums of squares (the layout s2i_colstats writes).  256 threads = cpb column quads x 256/cpb row lanes.
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slab, int S, long long rows,
                                                                   int N, float* __restrict__ y, int ldy,
-                                                                  float* __restrict__ part, int nparts, int cpb) {
+                                                                  float* __restrict__ part, int nparts, int cpb,
+                                                                  int ppg, long long Rg) {
   __shared__ f32x4 sh[2][256];
   const int tid = threadIdx.x;
   const int rpb = 256 / cpb;
   const int ql = tid % cpb, rl = tid / cpb;
   const int quad = blockIdx.y * cpb + ql;
   const int Q = N / 4;
-  const long long chunk = (rows + nparts - 1) / nparts;
-  const long long r0 = (long long)blockIdx.x * chunk;
-  const long long r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  const int grp = blockIdx.x / ppg, pp = blockIdx.x - grp * ppg;  // BatchNorm group of this row chunk
+  const long long chunk = (Rg + ppg - 1) / ppg;
+  const long long r0 = grp * Rg + pp * chunk;
+  const long long gend = (grp + 1) * Rg < rows ? (grp + 1) * Rg : rows;
+  const long long r1 = r0 + chunk < gend ? r0 + chunk : gend;
   const size_t sstride = (size_t)rows * N;
   f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (quad < Q) {
@@ -644,6 +647,12 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   }
   S2I_REQUIRE(d->ldy >= d->N, "conv: ldy < N");
   S2I_REQUIRE(!(d->stats && (d->act != S2I_ACT_NONE)), "conv: stats epilogue needs act NONE");
+  if (d->stats && d->groups > 1) {
+    // independent BatchNorm batches stacked along the rows: a 128-row tile must not straddle two of them
+    S2I_REQUIRE(d->kind != S2I_TCONV_K4S2 && (M % d->groups) == 0 && ((M / d->groups) % 128) == 0,
+                "conv: %lld rows do not split into %d BatchNorm groups of whole 128-row tiles", M, d->groups);
+    S2I_REQUIRE((d->N % 4) == 0, "conv: grouped statistics need N %% 4 == 0");
+  }
   pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
   const int BN = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
   pl->gridM = s2i_cdiv(M, 128);
@@ -725,10 +734,13 @@ extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
 }
 
 // number of rows the stats pass writes; split-K layers take the column-stats kernel instead
-static int stat_parts_for(const FwdPlan& pl) {
+static int stat_parts_for(const FwdPlan& pl, int groups) {
+  if (groups < 1) groups = 1;
   if (pl.splitk > 1) {
-    int np = s2i_cdiv(pl.Mrows, 8);  // split-K layers have few rows: keep the reduce+stats pass wide
-    return np > 512 ? 512 : np;
+    int ppg = s2i_cdiv(pl.Mrows / groups, 8);  // split-K layers have few rows: keep the reduce+stats pass wide
+    if (ppg > 512 / groups) ppg = 512 / groups;
+    if (ppg < 1) ppg = 1;
+    return ppg * groups;
   }
   return pl.gridM * pl.nphases;
 }
@@ -736,7 +748,7 @@ static int stat_parts_for(const FwdPlan& pl) {
 extern "C" int s2i_conv_stat_parts(const s2i_conv_desc* d) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return -1;
-  return stat_parts_for(pl);
+  return stat_parts_for(pl, d->groups);
 }
 
 extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
@@ -779,9 +791,11 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
       const int Q = d->N / 4;
       int cpb = 1;
       while (cpb < Q && cpb < 256) cpb <<= 1;
-      const int nparts = stat_parts_for(pl);
+      const int groups = d->groups < 1 ? 1 : d->groups;
+      const int nparts = stat_parts_for(pl, groups);
       hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(nparts, (Q + cpb - 1) / cpb), dim3(256), 0, st,
-                         (const float*)ws, pl.splitk, pl.Mrows, d->N, y, d->ldy, part, nparts, cpb);
+                         (const float*)ws, pl.splitk, pl.Mrows, d->N, y, d->ldy, part, nparts, cpb, nparts / groups,
+                         pl.Mrows / groups);
       S2I_LAUNCH_CHECK("splitk_reduce_stats");
       return 0;
     }
@@ -791,7 +805,7 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, pl.splitk,
                        pl.Mrows, d->N, bias, d->act, y, d->ldy);
     S2I_LAUNCH_CHECK("splitk_reduce");
-    if (d->stats) return s2i_colstats(y, pl.Mrows, d->N, d->ldy, part, stat_parts_for(pl), stream);
+    if (d->stats) return s2i_colstats(y, pl.Mrows, d->N, d->ldy, part, stat_parts_for(pl, 1), stream);
   }
   return 0;
 }

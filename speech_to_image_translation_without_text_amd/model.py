@@ -49,10 +49,10 @@ class _Fused(nn.Sequential):
     conv_at = 0
     bn_at = 1
 
-    def forward(self, x, cvec=None, residual=None):
+    def forward(self, x, cvec=None, residual=None, groups=1):
         conv, bn = self[self.conv_at], self[self.bn_at]
         return ops.ConvBnAct.apply(x, cvec, conv.weight, bn.weight, bn.bias, residual, self.kind, self.act,
-                                   _bn_state(bn), self.training)
+                                   _bn_state(bn), self.training, groups)
 
 
 class UpBlock(_Fused):
@@ -131,12 +131,12 @@ class EncodeImageBy16(nn.Sequential):
                        nn.LeakyReLU(0.2, inplace=False)]
         super().__init__(*layers)
 
-    def forward(self, x):
+    def forward(self, x, groups=1):
         h = ops.ConvAct.apply(x, self[0].weight, None, "k4s2", ACT_LRELU, self[0].out_channels)
         for ci in (2, 5, 8):
             bn = self[ci + 1]
             h = ops.ConvBnAct.apply(h, None, self[ci].weight, bn.weight, bn.bias, None, "k4s2", ACT_LRELU,
-                                    _bn_state(bn), self.training)
+                                    _bn_state(bn), self.training, groups)
         return h
 
 
@@ -155,15 +155,19 @@ class CA_NET(nn.Module):
         self.fc = nn.Linear(self.t_dim, self.ef_dim * 4, bias=True)
         self.relu = GLU()
 
-    def encode(self, text_embedding):
+    def _encode(self, text_embedding):
         B = text_embedding.shape[0]
         pre = ops.ConvAct.apply(text_embedding.reshape(B, 1, 1, self.t_dim), self.fc.weight, self.fc.bias, "k1",
                                 ACT_NONE, self.ef_dim * 4)
         h = ops.Glu2d.apply(pre.view(B, self.ef_dim * 4))
         return h[:, :self.ef_dim], h[:, self.ef_dim:], h
 
+    def encode(self, text_embedding):
+        mu, logvar, _ = self._encode(text_embedding)
+        return mu, logvar
+
     def forward(self, text_embedding, eps=None):
-        mu, logvar, h = self.encode(text_embedding)
+        mu, logvar, h = self._encode(text_embedding)
         if eps is None:
             # same generator the reference draws from (model.py:190-193): torch's global RNG of the device
             eps = torch.empty_like(mu).normal_()
@@ -305,16 +309,19 @@ class _DNet(nn.Module):
             self.jointConv = Block3x3_leakRelu(ndf * 8 + self.ef_dim, ndf * 8)
             self.uncond_logits = nn.Sequential(nn.Conv2d(ndf * 8, 1, kernel_size=4, stride=4), nn.Sigmoid())
 
-    def forward(self, x_var, c_code=None):
+    def forward(self, x_var, c_code=None, groups=1, need_features=True):
+        """`groups` > 1 (not part of the reference signature): x_var stacks that many independent batches
+        along dim 0 — the real / wrong / fake passes of trainer.py:390-392 in one launch per layer — and
+        every BatchNorm keeps separate statistics per batch, updating its running statistics in that order."""
         x = ops.ToNHWC.apply(x_var, 4)
-        x_code = self.img_code_s16(x)
+        x_code = self.img_code_s16(x, groups)
         for name in self._tower:
-            x_code = getattr(self, name)(x_code)
+            x_code = getattr(self, name)(x_code, groups=groups)
         B, C = x_code.shape[0], x_code.shape[3]
         # the reference flattens an NCHW map (model.py:428): keep that element order for callers
-        x_immediate = ops.ToNCHW.apply(x_code, C).reshape(B, -1)
+        x_immediate = ops.ToNCHW.apply(x_code, C).reshape(B, -1) if need_features else None
         if self.b_condition and c_code is not None:
-            h_c_code = self.jointConv(x_code, cvec=c_code.reshape(-1, self.ef_dim))
+            h_c_code = self.jointConv(x_code, cvec=c_code.reshape(-1, self.ef_dim), groups=groups)
         else:
             h_c_code = x_code
         output = ops.LogitHead.apply(h_c_code, self.logits[0].weight, self.logits[0].bias)

@@ -129,13 +129,13 @@ def _geom(kind, H, W):
     return H, W
 
 
-def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False):
+def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1):
     """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts)."""
     lib = _lib_ready()
     B, H, W, Cx = x.shape
     Cc = 0 if cvec is None else cvec.shape[1]
     Ho, Wo = _geom(kind, H, W)
-    d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N)
+    d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
     part, nparts = None, 0
     if stats:
@@ -245,7 +245,7 @@ def _split_input_grad(dx_full, Cc):
 
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training):
+    def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training, groups=1):
         lib = _lib_ready()
         x = x.contiguous()
         if cvec is not None:
@@ -253,13 +253,16 @@ class ConvBnAct(torch.autograd.Function):
         kind = _KIND[kind_name]
         packed = packed_weight(weight, PACK_UPFOLD if kind_name == "up" else PACK_PLAIN)
         Cout = weight.shape[0]
-        y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2], stats=training)
+        y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2], stats=training,
+                                   groups=groups)
         M = y.numel() // Cout
-        coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
+        if not training:
+            groups = 1
+        coef = torch.empty((groups, 4, Cout), dtype=torch.float32, device=x.device)
         rm, rv, nbt = bn_buffers
         if training:
-            check(lib.s2i_bn_finalize(ptr(part), nparts, Cout, M, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), ptr(nbt),
-                                      BN_MOMENTUM, BN_EPS, ptr(coef), stream()), "s2i_bn_finalize")
+            check(lib.s2i_bn_finalize(ptr(part), nparts, groups, Cout, M // groups, ptr(gamma), ptr(beta), ptr(rm),
+                                      ptr(rv), ptr(nbt), BN_MOMENTUM, BN_EPS, ptr(coef), stream()), "s2i_bn_finalize")
         else:
             check(lib.s2i_bn_eval_coeffs(Cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, ptr(coef), stream()),
                   "s2i_bn_eval_coeffs")
@@ -267,11 +270,12 @@ class ConvBnAct(torch.autograd.Function):
         out = torch.empty(y.shape[:-1] + (Cact,), dtype=torch.float32, device=x.device)
         if residual is not None:
             residual = residual.contiguous()
-        check(lib.s2i_bn_act_forward(ptr(y), M, Cout, ptr(coef), act, ptr(residual), ptr(out), stream()),
+        check(lib.s2i_bn_act_forward(ptr(y), M, groups, Cout, ptr(coef), act, ptr(residual), ptr(out), stream()),
               "s2i_bn_act_forward")
         ctx.save_for_backward(x, cvec, weight, gamma, y, coef)
         ctx.beta_ref = beta
         ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
+        ctx.groups = groups
         return out
 
     @staticmethod
@@ -283,21 +287,22 @@ class ConvBnAct(torch.autograd.Function):
         Cout = weight.shape[0]
         M = y.numel() // Cout
         dout_k, ldd = _rows_view(dout)
-        nparts = _num_parts(M)
+        G = ctx.groups
+        nparts = _num_parts(M // G) * G
         part = torch.empty((2, nparts, Cout), dtype=torch.float32, device=y.device)
-        check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ctx.act, ptr(part), nparts,
+        check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ctx.act, ptr(part), nparts,
                                         stream()), "s2i_bn_act_bwd_reduce")
         beta = ctx.beta_ref
         direct_bn = _direct(gamma) and _direct(beta)
         dgamma = gamma.grad if direct_bn else torch.empty_like(gamma)
         dbeta = beta.grad if direct_bn else torch.empty_like(gamma)
-        red2 = torch.empty((2, Cout), dtype=torch.float32, device=y.device)
-        check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, Cout, M, ptr(dgamma), ptr(dbeta), 1 if direct_bn else 0,
-                                      ptr(red2), stream()), "s2i_bn_bwd_finalize")
+        red2 = torch.empty((G, 2, Cout), dtype=torch.float32, device=y.device)
+        check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, G, Cout, M // G, ptr(dgamma), ptr(dbeta),
+                                      1 if direct_bn else 0, ptr(red2), stream()), "s2i_bn_bwd_finalize")
         if direct_bn:
             dgamma = dbeta = None
         dy = torch.empty_like(y)
-        check(lib.s2i_bn_act_bwd_apply(ptr(y), ptr(dout_k), ldd, M, Cout, ptr(coef), ptr(red2), ctx.act, ptr(dy),
+        check(lib.s2i_bn_act_bwd_apply(ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ptr(red2), ctx.act, ptr(dy),
                                        stream()), "s2i_bn_act_bwd_apply")
         need_x, need_c, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dc = dw = None
@@ -311,7 +316,7 @@ class ConvBnAct(torch.autograd.Function):
         if need_w:
             dw = _wgrad(ctx.kind_name, x, cvec, dy, weight)
         dres = dout if ctx.has_res else None
-        return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None
+        return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None
 
 
 class ConvAct(torch.autograd.Function):

@@ -221,6 +221,7 @@ class condGANTrainer(object):
         self.distributed = distributed
         self.world = torch.distributed.get_world_size() if distributed else 1
         self._pending = []
+        self.stack_d_passes = True
 
     # -- set-up -------------------------------------------------------------------------------------------
     def build(self, netG=None, netsD=None, start_count=0):
@@ -259,13 +260,23 @@ class condGANTrainer(object):
         return torch.distributed.all_reduce(flat.g, op=torch.distributed.ReduceOp.SUM, async_op=True)
 
     # -- D update (trainer.py:375-427) ----------------------------------------------------------------------------
-    def _d_loss(self, idx):
+    def _d_logits(self, idx):
+        """Conditional/unconditional probabilities of the real, wrong and fake batches.  When the batch is a
+        multiple of 8 (so that every layer's rows split into whole 128-row tiles per batch) the three passes run
+        as ONE stacked forward with per-batch BatchNorm statistics; otherwise as the reference's three calls."""
         netD = self.netsD[idx]
         mu = self.mu.detach()
+        B = mu.shape[0]
+        if self.stack_d_passes and B % 8 == 0:
+            x = torch.cat((self.real_imgs[idx], self.wrong_imgs[idx], self.fake_imgs[idx].detach()), 0)
+            logits, _ = _unwrap(netD)(x, mu.repeat(3, 1), groups=3, need_features=False)
+            return [[l[g * B:(g + 1) * B] for l in logits] for g in range(3)]
+        return [netD(self.real_imgs[idx], mu)[0], netD(self.wrong_imgs[idx], mu)[0],
+                netD(self.fake_imgs[idx].detach(), mu)[0]]
+
+    def _d_loss(self, idx):
         u = cfg.TRAIN.COEFF.UNCOND_LOSS
-        real_logits, _ = netD(self.real_imgs[idx], mu)
-        wrong_logits, _ = netD(self.wrong_imgs[idx], mu)
-        fake_logits, _ = netD(self.fake_imgs[idx].detach(), mu)
+        real_logits, wrong_logits, fake_logits = self._d_logits(idx)
         errD_real = ops.BCELoss.apply(real_logits[0], 1.0, 1.0)
         errD_wrong = ops.BCELoss.apply(wrong_logits[0], 0.0, 1.0)
         errD_fake = ops.BCELoss.apply(fake_logits[0], 0.0, 1.0)

@@ -205,3 +205,43 @@ def test_checkpoint_layout_roundtrip(gpu, tmp_path):
     for k, v in g2.state_dict().items():
         assert torch.equal(v.cpu(), sd[k].cpu()), k
     cfg.TRAIN.NET_G = cfg.TRAIN.NET_D = ''
+
+
+def test_stacked_d_passes_match_separate_and_oracle(gpu):
+    """The D update runs real / wrong / fake as ONE stacked forward with per-batch BatchNorm statistics
+    (batch a multiple of 8).  It must equal three separate calls (the reference's structure) and the oracle."""
+    import copy
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import trainer as T
+    case = dict(CASES['small3'], B=8)
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    ostate = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    oout = orc.train_step(ostate, batch, oracle_dims(case))
+    results = []
+    for stacked in (True, False):
+        g2, ds2 = copy.deepcopy(netG).to(gpu), [copy.deepcopy(d).to(gpu) for d in netsD]
+        tr = T.condGANTrainer(None, None, 256, False)
+        tr.build(g2, ds2)
+        tr.stack_d_passes = stacked
+        b = to_dev(batch, gpu)
+        errD, errG, kl = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'],
+                                       b['noise'], b['eps'])
+        torch.cuda.synchronize()
+        results.append((float(errD), float(errG), [{k: v.detach().cpu().clone() for k, v in d.state_dict().items()}
+                                                    for d in ds2]))
+        assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total stacked=%s" % stacked)
+        assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total stacked=%s" % stacked)
+        for i, d in enumerate(ds2):
+            for k, v in d.state_dict().items():
+                if k.endswith('num_batches_tracked'):
+                    assert int(v) == 4, (k, int(v))
+                elif k.endswith('running_mean') or k.endswith('running_var'):
+                    assert_close(v, ostate.ds[i][k], rtol=1e-3, atol=3e-4, what="D%d %s" % (i, k))
+    assert abs(results[0][0] - results[1][0]) <= 1e-4 * abs(results[1][0])
+    for sa, sb in zip(results[0][2], results[1][2]):
+        for k in sa:
+            if sa[k].is_floating_point():
+                err = (sa[k] - sb[k]).abs()
+                assert float(err.max()) <= 4.2e-4, (k, float(err.max()))
+                assert int((err > 5e-6).sum()) <= max(2, 0.05 * err.numel()), (k, int((err > 5e-6).sum()))
