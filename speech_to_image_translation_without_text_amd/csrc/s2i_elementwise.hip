@@ -149,13 +149,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       shd[(1 * 1024 + tid) * 4 + j] = a1[j];
     }
     __syncthreads();
-    if (pl == 0 && quad < Q) {
-      for (int r = 1; r < lanes; ++r)
+    // tree over the part lanes (thread tid = pl * qpb + ql; lanes is a power of two)
+    for (int sft = lanes >> 1; sft > 0; sft >>= 1) {
+      if (pl < sft) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          a0[j] += shd[(0 * 1024 + r * qpb + ql) * 4 + j];
-          a1[j] += shd[(1 * 1024 + r * qpb + ql) * 4 + j];
+          shd[(0 * 1024 + tid) * 4 + j] += shd[(0 * 1024 + tid + sft * qpb) * 4 + j];
+          shd[(1 * 1024 + tid) * 4 + j] += shd[(1 * 1024 + tid + sft * qpb) * 4 + j];
         }
+      }
+      __syncthreads();
+    }
+    if (pl == 0 && quad < Q) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0[j] = shd[(0 * 1024 + tid) * 4 + j];
+        a1[j] = shd[(1 * 1024 + tid) * 4 + j];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int c = quad * 4 + j;
@@ -641,8 +651,9 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
               groups);
   const int ppg = nparts / groups;
   const int Q = C / 4;
+  // quads per block: few for narrow layers (their partial lists are the long ones), up to 32 for wide layers
   int qpb = 1;
-  while (qpb < Q && qpb < 32) qpb <<= 1;
+  while (qpb < 32 && qpb * 32 < Q) qpb <<= 1;
   const int grid = (Q + qpb - 1) / qpb;
   const size_t shbytes = 2 * 1024 * 4 * sizeof(double);
   if (mode == 0)
