@@ -68,6 +68,7 @@ typedef struct s2i_conv_desc {
   int groups;    /* BatchNorm groups: the rows are `groups` equal, independent batches stacked along
                     the batch axis (real / wrong / fake passes of trainer.py:390-392 in one launch);
                     statistics are kept per group.  0 or 1 = one batch                           */
+  int nosplit;   /* 1: never split K (required with a class bias, s2i_conv_forward_cls)           */
 } s2i_conv_desc;
 
 /* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */
@@ -83,6 +84,29 @@ int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, 
                      const float* bias, float* y, float* part, void* ws, size_t ws_bytes,
                      void* stream);
 
+/* Same, plus `cls_bias` [B][9][N]: a per-image, per-border-class term added before the statistics
+   (the pre-reduced contribution of the broadcast c_code channels, see s2i_cvec_bias_table). */
+int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                         const float* bias, const float* cls_bias, float* y, float* part, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* ---- spatially constant channels of a 3x3 conv (c_code broadcast, model.py:272-279) -----------
+ * A channel that is constant over space contributes sum over the IN-BOUNDS taps of c*W: a bias that
+ * depends only on the image and on which borders the pixel touches (9 classes).  Forward: table
+ * [B][9][N] from c (B,Cc) and the packed weight rows [0,Cc).  Backward: border sums of dY give, per
+ * tap, the sum of dY over the pixels where the tap is in bounds; from them dc and dW[:, :Cc]. */
+int s2i_cvec_bias_table(const float* cvec, const float* packed, int B, int Cc, int Ip, int Op, int N,
+                        float* table, void* stream);
+size_t s2i_border_sums_workspace_bytes(int B, int H, int W, int C);
+/* tapsum[b][t][c] = sum of dy[b,y,x,c] over pixels where tap t (3x3, pad 1) is in bounds */
+int s2i_tap_sums(const float* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,
+                 void* stream);
+/* dc[b][cc] = sum_{t,co} P[t][cc][co]*tapsum[b][t][co];  dW[co][cc][t] (+)= sum_b c[b][cc]*tapsum[b][t][co]
+   (dW is the OIHW gradient of a parameter with I_total input channels, channels [0,Cc) written) */
+int s2i_cvec_grads(const float* cvec, const float* packed, const float* tapsum, int B, int Cc, int Ip,
+                   int Op, int N, int O, int I_total, float* dc, float* dw_oihw, int accumulate,
+                   void* stream);
+
 /* ---- weight gradient ------------------------------------------------------------------------ */
 typedef struct s2i_wgrad_desc {
   int kind;      /* geometry of the gather applied to `a`                                        */
@@ -95,6 +119,8 @@ typedef struct s2i_wgrad_desc {
   int fold;      /* 1: fold effective 4x4 taps back onto the 3x3 parameter (S2I_PACK_UPFOLD)    */
   int O, I, KH, KW; /* shape of the OIHW gradient tensor written                                */
   int accumulate;   /* 1: grad += result, 0: grad = result                                      */
+  int i_off;        /* the I input channels computed here are channels [i_off, i_off+I) of a       */
+  int I_total;      /* parameter with I_total input channels (0 = I): the c_code / h_code split    */
 } s2i_wgrad_desc;
 
 size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);

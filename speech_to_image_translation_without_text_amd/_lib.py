@@ -23,12 +23,12 @@ c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Cx", "Cc", "N", "wmode", "flip", "wR",
-                                     "ldw", "act", "stats", "ldy", "groups")]
+                                     "ldw", "act", "stats", "ldy", "groups", "nosplit")]
 
 
 class WgradDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Ca", "Cc", "N", "ldg", "swap", "fold",
-                                     "O", "I", "KH", "KW", "accumulate")]
+                                     "O", "I", "KH", "KW", "accumulate", "i_off", "I_total")]
 
 
 P = c_void_p
@@ -39,6 +39,11 @@ _SIGNATURES = {
     "s2i_conv_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, c_size_t, P]),
+    "s2i_conv_forward_cls": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
+    "s2i_cvec_bias_table": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "s2i_border_sums_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "s2i_tap_sums": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "s2i_cvec_grads": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_int, P]),
     "s2i_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "s2i_conv_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P, c_size_t, P]),
     "s2i_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),

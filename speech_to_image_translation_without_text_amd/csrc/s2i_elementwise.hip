@@ -400,6 +400,119 @@ __global__ void spatial_sum_stage2(const float* __restrict__ tmp, int B, int S, 
   dst[e] = v;
 }
 
+// ---- spatially constant channels of a 3x3 conv --------------------------------------------------
+// valid taps of border class cls = 3*ry + rx (ry: 0 top, 1 middle, 2 bottom): ky in [ry==0, 2-(ry==2)]
+__global__ void cvec_bias_table_kernel(const float* __restrict__ cvec, const float* __restrict__ packed, int B, int Cc,
+                                       int Ip, int Op, int N, float* __restrict__ table) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * 9 * N) return;
+  const int n = e % N;
+  const int cls = (e / N) % 9;
+  const int b = e / (9 * N);
+  const int ry = cls / 3, rx = cls - ry * 3;
+  const int ky0 = ry == 0 ? 1 : 0, ky1 = ry == 2 ? 1 : 2, kx0 = rx == 0 ? 1 : 0, kx1 = rx == 2 ? 1 : 2;
+  float acc = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) {
+      const float* wp = packed + ((size_t)(ky * 3 + kx) * Ip) * Op + n;
+      for (int cc = 0; cc < Cc; ++cc) acc += cvec[b * Cc + cc] * wp[(size_t)cc * Op];
+    }
+  table[e] = acc;
+}
+
+// stage 1: per image and row band, 9 border sums per channel:
+//   0 total, 1 row y=0, 2 row y=H-1, 3 col x=0, 4 col x=W-1, 5..8 corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+__global__ __launch_bounds__(256) void border_sums_stage1(const float* __restrict__ dy, int H, int W, int C, int S,
+                                                          float* __restrict__ tmp, int cpb) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.z * cpb + ql;
+  const int Q = C / 4;
+  const int b = blockIdx.x, sidx = blockIdx.y;
+  const int band = (H + S - 1) / S;
+  const int y0 = sidx * band, y1 = min(H, y0 + band);
+  f32x4 a[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) a[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (quad < Q) {
+    for (int y = y0; y < y1; ++y) {
+      const bool top = y == 0, bot = y == H - 1;
+      for (int x = rl; x < W; x += rpb) {
+        const f32x4 v = ld4(dy + (((long long)b * H + y) * W + x) * C + quad * 4);
+        const bool lft = x == 0, rgt = x == W - 1;
+        a[0] += v;
+        if (top) a[1] += v;
+        if (bot) a[2] += v;
+        if (lft) a[3] += v;
+        if (rgt) a[4] += v;
+        if (top && lft) a[5] += v;
+        if (top && rgt) a[6] += v;
+        if (bot && lft) a[7] += v;
+        if (bot && rgt) a[8] += v;
+      }
+    }
+  }
+  for (int k = 0; k < 9; ++k) {
+    __syncthreads();
+    sh[tid] = a[k];
+    __syncthreads();
+    if (rl == 0 && quad < Q) {
+      f32x4 v = a[k];
+      for (int r = 1; r < rpb; ++r) v += sh[r * cpb + ql];
+      st4(tmp + (((size_t)b * S + sidx) * 9 + k) * C + quad * 4, v);
+    }
+  }
+}
+// stage 2: sum the bands, then tapsum[b][t][c] = total - excluded row - excluded col + excluded corner
+__global__ void border_sums_stage2(const float* __restrict__ tmp, int B, int S, int C, float* __restrict__ tapsum) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, c = e - b * C;
+  float v[9];
+  for (int k = 0; k < 9; ++k) {
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += tmp[(((size_t)b * S + s) * 9 + k) * C + c];
+    v[k] = acc;
+  }
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      // tap (ky,kx) is out of bounds on row y=0 when ky==0, on row H-1 when ky==2; same for columns
+      const int er = ky == 0 ? 1 : (ky == 2 ? 2 : 0), ec = kx == 0 ? 3 : (kx == 2 ? 4 : 0);
+      float r = v[0];
+      if (er) r -= v[er];
+      if (ec) r -= v[ec];
+      if (er && ec) r += v[5 + (er == 2 ? 2 : 0) + (ec == 4 ? 1 : 0)];
+      tapsum[((size_t)b * 9 + ky * 3 + kx) * C + c] = r;
+    }
+}
+__global__ void cvec_dc_kernel(const float* __restrict__ packed, const float* __restrict__ tapsum, int B, int Cc, int Ip,
+                               int Op, int N, float* __restrict__ dc) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * Cc) return;
+  const int b = e / Cc, cc = e - b * Cc;
+  float acc = 0.f;
+  for (int t = 0; t < 9; ++t) {
+    const float* wp = packed + ((size_t)t * Ip + cc) * Op;
+    const float* sp = tapsum + ((size_t)b * 9 + t) * N;
+    for (int n = 0; n < N; ++n) acc += wp[n] * sp[n];
+  }
+  dc[e] = acc;
+}
+__global__ void cvec_dw_kernel(const float* __restrict__ cvec, const float* __restrict__ tapsum, int B, int Cc, int N,
+                               int O, int I_total, float* __restrict__ dw, int accumulate) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= O * Cc * 9) return;
+  const int t = e % 9;
+  const int cc = (e / 9) % Cc;
+  const int o = e / (9 * Cc);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += cvec[b * Cc + cc] * tapsum[((size_t)b * 9 + t) * N + o];
+  float* gp = dw + ((size_t)o * I_total + cc) * 9 + t;
+  *gp = accumulate ? *gp + acc : acc;
+}
+
 // ---- CA_NET ------------------------------------------------------------------------------------
 __global__ void reparam_fwd_kernel(const float* __restrict__ h, const float* __restrict__ eps, int B, int E,
                                    float* __restrict__ c) {
@@ -789,6 +902,53 @@ extern "C" int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, f
   S2I_LAUNCH_CHECK("spatial_sum_stage1");
   hipLaunchKernelGGL(spatial_sum_stage2, dim3((B * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, S, C, dst);
   S2I_LAUNCH_CHECK("spatial_sum_stage2");
+  return 0;
+}
+
+extern "C" int s2i_cvec_bias_table(const float* cvec, const float* packed, int B, int Cc, int Ip, int Op, int N,
+                                   float* table, void* stream) {
+  S2I_REQUIRE(cvec && packed && table && B > 0 && Cc > 0 && Cc <= Ip && N > 0 && N <= Op, "cvec_bias_table: bad args");
+  hipLaunchKernelGGL(cvec_bias_table_kernel, dim3((B * 9 * N + 255) / 256), dim3(256), 0, ST, cvec, packed, B, Cc, Ip,
+                     Op, N, table);
+  S2I_LAUNCH_CHECK("cvec_bias_table");
+  return 0;
+}
+static int border_segments(int H) {
+  int S = H / 4;
+  if (S > 32) S = 32;
+  if (S < 1) S = 1;
+  return S;
+}
+extern "C" size_t s2i_border_sums_workspace_bytes(int B, int H, int W, int C) {
+  return (size_t)B * border_segments(H) * 9 * C * sizeof(float);
+}
+extern "C" int s2i_tap_sums(const float* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,
+                            void* stream) {
+  S2I_REQUIRE(dy && tapsum && B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "tap_sums: bad args");
+  const int S = border_segments(H);
+  S2I_REQUIRE(ws && ws_bytes >= (size_t)B * S * 9 * C * sizeof(float), "tap_sums: workspace too small");
+  RedGeom g = red_geom(C);
+  hipLaunchKernelGGL(border_sums_stage1, dim3(B, S, g.gy), dim3(256), 0, ST, dy, H, W, C, S, (float*)ws, g.cpb);
+  S2I_LAUNCH_CHECK("border_sums_stage1");
+  hipLaunchKernelGGL(border_sums_stage2, dim3((B * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, S, C,
+                     tapsum);
+  S2I_LAUNCH_CHECK("border_sums_stage2");
+  return 0;
+}
+extern "C" int s2i_cvec_grads(const float* cvec, const float* packed, const float* tapsum, int B, int Cc, int Ip, int Op,
+                              int N, int O, int I_total, float* dc, float* dw_oihw, int accumulate, void* stream) {
+  S2I_REQUIRE(cvec && packed && tapsum && B > 0 && Cc > 0 && Cc <= Ip && N > 0 && N <= Op && O <= N && I_total >= Cc,
+              "cvec_grads: bad args");
+  if (dc) {
+    hipLaunchKernelGGL(cvec_dc_kernel, dim3((B * Cc + 255) / 256), dim3(256), 0, ST, packed, tapsum, B, Cc, Ip, Op, N,
+                       dc);
+    S2I_LAUNCH_CHECK("cvec_dc");
+  }
+  if (dw_oihw) {
+    hipLaunchKernelGGL(cvec_dw_kernel, dim3((O * Cc * 9 + 255) / 256), dim3(256), 0, ST, cvec, tapsum, B, Cc, N, O,
+                       I_total, dw_oihw, accumulate);
+    S2I_LAUNCH_CHECK("cvec_dw");
+  }
   return 0;
 }
 

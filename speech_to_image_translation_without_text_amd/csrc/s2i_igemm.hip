@@ -26,6 +26,7 @@ struct IgemmP {
   const float* __restrict__ cvec;
   const float* __restrict__ w;
   const float* __restrict__ bias;
+  const float* __restrict__ cls_bias;
   float* __restrict__ y;
   float* __restrict__ part;
   float* __restrict__ slab;
@@ -264,6 +265,27 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   const int l31 = lane & 31, lh = lane >> 5;
   const bool tconv = p.kind == S2I_TCONV_K4S2;
   const bool raw = p.splitk > 1;
+  if (p.cls_bias && !raw) {
+    // contribution of a spatially constant operand (the broadcast c_code of model.py:277), pre-reduced per
+    // border class: cls = 3 * (top | middle | bottom) + (left | middle | right)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const int b = m >> p.lgHoWo;
+        const int rr = m & ((1 << p.lgHoWo) - 1);
+        const int oy = rr >> p.lgWo, ox = rr & (p.Wo - 1);
+        const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+        const float* bp = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) acc[i][j][r] += bp[n];
+        }
+      }
+  }
   float* outp = raw ? p.slab + (size_t)split * p.Mrows * p.N : p.y;
   const int ldo = raw ? p.N : p.ldy;
 #pragma unroll
@@ -523,7 +545,8 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ slab,
 //   non-swap: slab rows (tap, cin), columns cout;   swap: slab rows (tap, cout), columns cin.
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ slab, int S, int K, int N,
                                                            int Cg, int O, int I, int Tp, int T, int swap, int fold,
-                                                           int accumulate, int RT, float* __restrict__ grad) {
+                                                           int accumulate, int RT, float* __restrict__ grad,
+                                                           int i_off, int I_total) {
   extern __shared__ float tile[];  // [T][RT][33]
   const int tid = threadIdx.x;
   const int ncols = swap ? I : O, nrows = swap ? O : I;
@@ -567,7 +590,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     } else {
       v = tile[(tapo * RT + r_l) * 33 + c_l];
     }
-    float* gp = grad + ((size_t)o * I + i) * Tp + tapo;
+    float* gp = grad + ((size_t)o * I_total + i_off + i) * Tp + tapo;
     *gp = accumulate ? *gp + v : v;
   }
 }
@@ -639,7 +662,7 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   pl->Mrows = M * pl->nphases;
   pl->K = pl->T * pl->Ca;
   if (d->wmode == 0) {
-    S2I_REQUIRE(d->wR == pl->Ca, "conv: wR (%d) must equal gathered channels (%d)", d->wR, pl->Ca);
+    S2I_REQUIRE(d->wR >= pl->Ca, "conv: wR (%d) smaller than the gathered channels (%d)", d->wR, pl->Ca);
     S2I_REQUIRE(d->ldw >= d->N && d->ldw % 4 == 0, "conv: ldw %d too small for N %d", d->ldw, d->N);
   } else {
     S2I_REQUIRE(d->wR >= d->N, "conv(T): wR (%d) < N (%d)", d->wR, d->N);
@@ -660,7 +683,7 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   pl->nchunks = s2i_cdiv(pl->K, 32);
   const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
   int splitk = 1;
-  if (blocks < 512 && pl->nchunks >= 16) {
+  if (blocks < 512 && pl->nchunks >= 16 && !d->nosplit) {
     // three 256-thread blocks fit per CU: split K until about 768 blocks exist
     splitk = (int)(768 / blocks);
     if (splitk > pl->nchunks / 8) splitk = pl->nchunks / 8;
@@ -754,8 +777,15 @@ extern "C" int s2i_conv_stat_parts(const s2i_conv_desc* d) {
 extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                                 const float* bias, float* y, float* part, void* ws, size_t ws_bytes,
                                 void* stream) {
+  return s2i_conv_forward_cls(d, x, cvec, w, bias, nullptr, y, part, ws, ws_bytes, stream);
+}
+
+extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                                    const float* bias, const float* cls_bias, float* y, float* part, void* ws,
+                                    size_t ws_bytes, void* stream) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 1;
+  S2I_REQUIRE(!cls_bias || (d->kind == S2I_CONV_K3S1 && pl.splitk == 1), "conv: class bias needs an unsplit 3x3 conv");
   S2I_REQUIRE(x != nullptr || d->Cx == 0, "conv: x is null");
   S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "conv: cvec is null but Cc > 0");
   S2I_REQUIRE(w && y, "conv: null weight/output");
@@ -764,7 +794,7 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
   S2I_REQUIRE(ws_bytes >= need && (need == 0 || ws), "conv: workspace too small (%zu < %zu)", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   IgemmP p;
-  p.x = x; p.cvec = cvec; p.w = w; p.bias = bias; p.y = y; p.part = part; p.slab = (float*)ws;
+  p.x = x; p.cvec = cvec; p.w = w; p.bias = bias; p.cls_bias = cls_bias; p.y = y; p.part = part; p.slab = (float*)ws;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cx = d->Cx; p.Cc = d->Cc; p.Ca = pl.Ca;
   p.Ho = pl.Ho; p.Wo = pl.Wo; p.lgWo = s2i_ilog2(pl.Wo); p.lgHoWo = s2i_ilog2(pl.Ho * pl.Wo);
   p.M = pl.M; p.N = d->N; p.K = pl.K; p.T = pl.T;
@@ -859,7 +889,8 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
       S = 1;
     }
     hipLaunchKernelGGL(wgrad_finish_kernel, fgrid, dim3(256), shb, st, (const float*)ws, S, pl.K, d->N,
-                       pl.Cin, d->O, d->I, d->KH * d->KW, pl.T, d->swap, d->fold, d->accumulate, RT, grad_oihw);
+                       pl.Cin, d->O, d->I, d->KH * d->KW, pl.T, d->swap, d->fold, d->accumulate, RT, grad_oihw,
+                       d->i_off, d->I_total > 0 ? d->I_total : d->I);
   }
   S2I_LAUNCH_CHECK("wgrad_finish");
   return 0;

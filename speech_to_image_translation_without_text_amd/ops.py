@@ -129,13 +129,17 @@ def _geom(kind, H, W):
     return H, W
 
 
-def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1):
-    """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts)."""
+def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1,
+             w_offset=0, cls_bias=None):
+    """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts).
+    w_offset (floats) skips leading weight rows (the c_code rows of a jointConv); cls_bias [B][9][N]
+    adds their pre-reduced contribution per border class."""
     lib = _lib_ready()
     B, H, W, Cx = x.shape
     Cc = 0 if cvec is None else cvec.shape[1]
     Ho, Wo = _geom(kind, H, W)
-    d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups)
+    d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
+                 1 if cls_bias is not None else 0)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
     part, nparts = None, 0
     if stats:
@@ -145,13 +149,15 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
         part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
     wsb = lib.s2i_conv_workspace_bytes(ctypes.byref(d))
     ws = _ws.get(wsb, x.device)
-    check(lib.s2i_conv_forward(ctypes.byref(d), ptr(x), ptr(cvec), ptr(packed), ptr(bias), ptr(y), ptr(part),
-                               ptr(ws), ws.numel() * 4, stream()), "s2i_conv_forward")
+    wp = ptr(packed) + 4 * int(w_offset)
+    check(lib.s2i_conv_forward_cls(ctypes.byref(d), ptr(x), ptr(cvec), wp, ptr(bias), ptr(cls_bias), ptr(y), ptr(part),
+                                   ptr(ws), ws.numel() * 4, stream()), "s2i_conv_forward")
     return y, part, nparts
 
 
-def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False):
-    """Weight gradient into an OIHW tensor of shape grad_shape.  a: gathered NHWC, g: plain NHWC."""
+def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False, i_off=0, I_total=0):
+    """Weight gradient into an OIHW tensor of shape grad_shape.  a: gathered NHWC, g: plain NHWC.
+    With I_total > 0 only input channels [i_off, i_off + I) of a wider (O, I_total, KH, KW) tensor are written."""
     lib = _lib_ready()
     B, H, W, Ca = a.shape
     Cc = 0 if cvec is None else cvec.shape[1]
@@ -160,9 +166,10 @@ def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumul
         O, I, KH, KW = grad_shape[0], grad_shape[1], 1, 1
     else:
         O, I, KH, KW = grad_shape
-    d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0)
+    d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0, i_off, I_total)
     if out is None:
-        out = torch.empty(grad_shape, dtype=torch.float32, device=a.device)
+        full = grad_shape if not I_total else (O, I_total, KH, KW)
+        out = torch.empty(full, dtype=torch.float32, device=a.device)
     wsb = lib.s2i_wgrad_workspace_bytes(ctypes.byref(d))
     if wsb == 0:
         check(1, "s2i_wgrad_workspace_bytes")
@@ -243,6 +250,23 @@ def _split_input_grad(dx_full, Cc):
     return dx_full[..., Cc:], dc
 
 
+def _factor_cvec(kind_name, cvec, x):
+    """Spatially constant channels of a 3x3 conv are folded into a per-image, per-border-class bias (and
+    their gradients taken from border sums of dY) instead of being convolved: on G's jointConv layers
+    (model.py:268, 272-279) they are 128 of 192 / 160 input channels."""
+    return cvec is not None and kind_name == "k3s1" and x.shape[1] >= 16 and x.shape[2] >= 16 and cvec.shape[1] % 4 == 0
+
+
+def _tap_sums(dy):
+    lib = _lib_ready()
+    B, H, W, C = dy.shape
+    out = torch.empty((B, 9, C), dtype=torch.float32, device=dy.device)
+    wsb = lib.s2i_border_sums_workspace_bytes(B, H, W, C)
+    ws = _ws.get(wsb, dy.device)
+    check(lib.s2i_tap_sums(ptr(dy), B, H, W, C, ptr(out), ptr(ws), ws.numel() * 4, stream()), "s2i_tap_sums")
+    return out
+
+
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training, groups=1):
@@ -253,8 +277,18 @@ class ConvBnAct(torch.autograd.Function):
         kind = _KIND[kind_name]
         packed = packed_weight(weight, PACK_UPFOLD if kind_name == "up" else PACK_PLAIN)
         Cout = weight.shape[0]
-        y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2], stats=training,
-                                   groups=groups)
+        factored = _factor_cvec(kind_name, cvec, x)
+        if factored:
+            B, Cc = cvec.shape
+            Ip, Op = packed.shape[1], packed.shape[2]
+            table = torch.empty((B, 9, Cout), dtype=torch.float32, device=x.device)
+            check(lib.s2i_cvec_bias_table(ptr(cvec), ptr(packed), B, Cc, Ip, Op, Cout, ptr(table), stream()),
+                  "s2i_cvec_bias_table")
+            y, part, nparts = conv_raw(kind, x, None, packed, Cout, wR=Ip, ldw=Op, stats=training, groups=groups,
+                                       w_offset=Cc * Op, cls_bias=table)
+        else:
+            y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2],
+                                       stats=training, groups=groups)
         M = y.numel() // Cout
         if not training:
             groups = 1
@@ -276,6 +310,7 @@ class ConvBnAct(torch.autograd.Function):
         ctx.beta_ref = beta
         ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
         ctx.groups = groups
+        ctx.factored = factored
         return out
 
     @staticmethod
@@ -307,13 +342,32 @@ class ConvBnAct(torch.autograd.Function):
         need_x, need_c, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dc = dw = None
         Cc = 0 if cvec is None else cvec.shape[1]
-        if need_x or (need_c and cvec is not None):
+        if ctx.factored:
+            packed = packed_weight(weight, PACK_PLAIN)
+            Ip, Op = packed.shape[1], packed.shape[2]
+            B, Cx = x.shape[0], x.shape[-1]
+            if need_x:
+                dx, _, _ = conv_raw(CONV_K3S1, dy, None, packed, Cx, wmode=1, flip=1, wR=Ip, ldw=Op, w_offset=Cc * Op)
+            if need_c or need_w:
+                tapsum = _tap_sums(dy)
+                direct = need_w and _direct(weight)
+                if need_w:
+                    dw = weight.grad if direct else torch.empty(tuple(weight.shape), dtype=torch.float32, device=x.device)
+                    wgrad_raw(CONV_K3S1, x, None, dy, (Cout, Cx, 3, 3), out=dw, accumulate=direct, i_off=Cc,
+                              I_total=Cc + Cx)
+                if need_c:
+                    dc = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+                check(lib.s2i_cvec_grads(ptr(cvec), ptr(packed), ptr(tapsum), B, Cc, Ip, Op, Cout, Cout, Cc + Cx, ptr(dc),
+                                         ptr(dw) if need_w else None, 1 if direct else 0, stream()), "s2i_cvec_grads")
+                if direct:
+                    dw = None
+        elif need_x or (need_c and cvec is not None):
             packed = packed_weight(weight, PACK_UPFOLD if ctx.kind_name == "up" else PACK_PLAIN)
             dx_full = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1] + Cc)
             dx, dc = _split_input_grad(dx_full, Cc)
             if not need_x:
                 dx = None
-        if need_w:
+        if need_w and not ctx.factored:
             dw = _wgrad(ctx.kind_name, x, cvec, dy, weight)
         dres = dout if ctx.has_res else None
         return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None

@@ -67,7 +67,8 @@ ACT = {"none": 0, "glu": 1, "lrelu": 2, "tanh": 3}
 CASES = [
     # kind, B, H, Cx, Cc, Cout, act, residual
     ("k3s1", 2, 8, 16, 0, 32, "glu", False),
-    ("k3s1", 3, 16, 8, 8, 24, "glu", False),      # broadcast vector concatenated first
+    ("k3s1", 3, 16, 8, 8, 24, "glu", False),      # broadcast vector concatenated first (factored path)
+    ("k3s1", 2, 32, 32, 128, 64, "glu", False),   # G jointConv shape class: c_code folded into a class bias
     ("k3s1", 2, 8, 16, 0, 16, "none", True),       # ResBlock second half
     ("k3s1", 4, 4, 160, 0, 64, "lrelu", False),    # D tail: tiny map, big K -> split-K
     ("k3s1", 4, 4, 128, 32, 64, "lrelu", False),   # D jointConv with c_code
@@ -94,7 +95,8 @@ CASES = [
 def test_conv_bn_act_fwd_bwd(gpu, case):
     from speech_to_image_translation_without_text_amd import ops
     kind, B, H, Cx, Cc, Cout, act, use_res = case
-    g = torch.Generator().manual_seed(hash(case) % 100000)
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 100000)  # stable across processes
     kk = {"k3s1": 3, "k4s2": 4, "up": 3, "k1": 1}[kind]
     x = torch.randn(B, Cx, H, H, generator=g)
     cvec = torch.randn(B, Cc, generator=g) if Cc else None
