@@ -350,7 +350,9 @@ class condGANTrainer(object):
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
         errD_total = 0
-        for i in range(self.num_Ds):
+        # the D updates are independent of each other: largest first, so that its gradient all-reduce
+        # (285 MB for D_NET256) hides behind the smaller discriminators' forward/backward
+        for i in reversed(range(self.num_Ds)):
             errD_total = errD_total + self.train_Dnet(i, 0, defer_step=True)
         self._flush_d_steps()
         kl_loss, errG_total = self.train_Gnet(0)
