@@ -205,6 +205,59 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
 }
 
+// Same result for short partial lists (<= 64 rows per group, the common case): one thread per channel, no
+// LDS, no barriers.  Launch-latency-bound layers get their statistics ~3x sooner than from the tree above.
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_finalize_small_kernel(const float* __restrict__ part, int ppg, int G, int C,
+                                                                double count, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, float momentum, float eps,
+                                                                float* __restrict__ out, float* __restrict__ dgamma,
+                                                                float* __restrict__ dbeta, int accumulate,
+                                                                long long* __restrict__ nbt) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (MODE == 0 && nbt && c == 0) nbt[0] += G;
+  if (c >= C) return;
+  const int nparts = ppg * G;
+  double g0 = 0, g1 = 0;
+  float rm = 0.f, rv = 0.f;
+  if (MODE == 0 && rmean) { rm = rmean[c]; rv = rvar[c]; }
+  for (int grp = 0; grp < G; ++grp) {
+    double a0 = 0, a1 = 0;
+    for (int pi = grp * ppg; pi < (grp + 1) * ppg; ++pi) {
+      a0 += part[((size_t)0 * nparts + pi) * C + c];
+      a1 += part[((size_t)1 * nparts + pi) * C + c];
+    }
+    if (MODE == 0) {
+      float* o = out + (size_t)grp * 4 * C;
+      const double mean = a0 / count;
+      double var = a1 / count - mean * mean;
+      if (var < 0) var = 0;
+      const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float sc = gamma[c] * invstd;
+      o[c] = (float)mean;
+      o[C + c] = invstd;
+      o[2 * C + c] = sc;
+      o[3 * C + c] = beta[c] - (float)mean * sc;
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      rm = (1.f - momentum) * rm + momentum * (float)mean;
+      rv = (1.f - momentum) * rv + momentum * (float)unb;
+    } else {
+      float* o = out + (size_t)grp * 2 * C;
+      o[c] = (float)(a0 / count);
+      o[C + c] = (float)(a1 / count);
+      g0 += a0;
+      g1 += a1;
+    }
+  }
+  if (MODE == 0) {
+    if (rmean) { rmean[c] = rm; rvar[c] = rv; }
+  } else {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)g0 : (float)g0;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)g1 : (float)g1;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                       const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
                                       float* __restrict__ out) {
@@ -763,6 +816,17 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
   S2I_REQUIRE(groups >= 1 && nparts % groups == 0, "bn finalize: %d partial rows do not split into %d groups", nparts,
               groups);
   const int ppg = nparts / groups;
+  if (ppg <= 64) {
+    const int grid = (C + 255) / 256;
+    if (mode == 0)
+      hipLaunchKernelGGL((bn_finalize_small_kernel<0>), dim3(grid), dim3(256), 0, ST, part, ppg, groups, C, (double)count,
+                         gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, nbt);
+    else
+      hipLaunchKernelGGL((bn_finalize_small_kernel<1>), dim3(grid), dim3(256), 0, ST, part, ppg, groups, C, (double)count,
+                         gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, nbt);
+    S2I_LAUNCH_CHECK("bn_finalize_small");
+    return 0;
+  }
   const int Q = C / 4;
   // quads per block: few for narrow layers (their partial lists are the long ones), up to 32 for wide layers
   int qpb = 1;

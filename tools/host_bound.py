@@ -1,0 +1,30 @@
+"""Is the step host-bound?  Compares the time Python needs to enqueue a step with the GPU time of the step."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from speech_to_image_translation_without_text_amd import model, trainer as T
+from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
+dev = torch.device("cuda:0"); B = 24
+cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
+torch.manual_seed(0)
+netG = model.G_NET(); netG.apply(T.weights_init)
+netsD = [c() for c in (model.D_NET64, model.D_NET128, model.D_NET256)]
+[d.apply(T.weights_init) for d in netsD]
+netG.to(dev); [d.to(dev) for d in netsD]
+tr = T.condGANTrainer(None, None, 256, False); tr.build(netG, netsD)
+g = torch.Generator(device=dev).manual_seed(1)
+real = [torch.rand(B, 3, 64 << i, 64 << i, device=dev, generator=g) * 2 - 1 for i in range(3)]
+wrong = [torch.rand(B, 3, 64 << i, 64 << i, device=dev, generator=g) * 2 - 1 for i in range(3)]
+emb = torch.randn(B, 1024, device=dev, generator=g); labels = (torch.arange(B, device=dev) % 3).to(torch.int32)
+noise = torch.randn(B, 100, device=dev, generator=g); eps = torch.randn(B, 128, device=dev, generator=g)
+step = lambda: tr.train_step(real, wrong, emb.detach().requires_grad_(True), labels, noise, eps)
+for _ in range(5): step()
+torch.cuda.synchronize()
+enq, tot = [], []
+for _ in range(10):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    step(); t1 = time.perf_counter()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+print("enqueue ms: %.2f (min %.2f)   step ms: %.2f (min %.2f)" % (sum(enq) / 10, min(enq), sum(tot) / 10, min(tot)))
