@@ -96,7 +96,7 @@ int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cv
  * [B][9][N] from c (B,Cc) and the packed weight rows [0,Cc).  Backward: border sums of dY give, per
  * tap, the sum of dY over the pixels where the tap is in bounds; from them dc and dW[:, :Cc]. */
 int s2i_cvec_bias_table(const float* cvec, const float* packed, int B, int Cc, int Ip, int Op, int N,
-                        float* table, void* stream);
+                        float* table, void* ws /* >= B*9*N floats */, size_t ws_bytes, void* stream);
 size_t s2i_border_sums_workspace_bytes(int B, int H, int W, int C);
 /* tapsum[b][t][c] = sum of dy[b,y,x,c] over pixels where tap t (3x3, pad 1) is in bounds */
 int s2i_tap_sums(const float* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,

@@ -205,8 +205,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
   }
 }
 
-// Same result for short partial lists (<= 64 rows per group, the common case): one thread per channel, no
-// LDS, no barriers.  Launch-latency-bound layers get their statistics ~3x sooner than from the tree above.
+// Same result for very short partial lists (<= 8 rows per group): one thread per channel, no LDS, no barriers.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_finalize_small_kernel(const float* __restrict__ part, int ppg, int G, int C,
                                                                 double count, const float* __restrict__ gamma,
@@ -455,8 +454,30 @@ __global__ void spatial_sum_stage2(const float* __restrict__ tmp, int B, int S, 
 
 // ---- spatially constant channels of a 3x3 conv --------------------------------------------------
 // valid taps of border class cls = 3*ry + rx (ry: 0 top, 1 middle, 2 bottom): ky in [ry==0, 2-(ry==2)]
-__global__ void cvec_bias_table_kernel(const float* __restrict__ cvec, const float* __restrict__ packed, int B, int Cc,
-                                       int Ip, int Op, int N, float* __restrict__ table) {
+// one block per (image, tap): T[b][t][n] = sum_cc c[b][cc] * P[t][cc][n]; c in LDS, n across threads
+__global__ __launch_bounds__(256) void cvec_tap_table_kernel(const float* __restrict__ cvec,
+                                                             const float* __restrict__ packed, int Cc, int Ip, int Op,
+                                                             int N, float* __restrict__ taps) {
+  extern __shared__ float cs[];
+  const int b = blockIdx.x / 9, t = blockIdx.x - b * 9;
+  for (int i = threadIdx.x; i < Cc; i += 256) cs[i] = cvec[b * Cc + i];
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float* wp = packed + ((size_t)t * Ip) * Op + n;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int cc = 0;
+    for (; cc + 3 < Cc; cc += 4) {
+      a0 += cs[cc] * wp[(size_t)cc * Op];
+      a1 += cs[cc + 1] * wp[(size_t)(cc + 1) * Op];
+      a2 += cs[cc + 2] * wp[(size_t)(cc + 2) * Op];
+      a3 += cs[cc + 3] * wp[(size_t)(cc + 3) * Op];
+    }
+    for (; cc < Cc; ++cc) a0 += cs[cc] * wp[(size_t)cc * Op];
+    taps[((size_t)b * 9 + t) * N + n] = (a0 + a1) + (a2 + a3);
+  }
+}
+// valid taps of border class cls = 3*ry + rx (ry: 0 top, 1 middle, 2 bottom): ky in [ry==0, 2-(ry==2)]
+__global__ void cvec_bias_table_kernel(const float* __restrict__ taps, int B, int N, float* __restrict__ table) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * 9 * N) return;
   const int n = e % N;
@@ -466,10 +487,7 @@ __global__ void cvec_bias_table_kernel(const float* __restrict__ cvec, const flo
   const int ky0 = ry == 0 ? 1 : 0, ky1 = ry == 2 ? 1 : 2, kx0 = rx == 0 ? 1 : 0, kx1 = rx == 2 ? 1 : 2;
   float acc = 0.f;
   for (int ky = ky0; ky <= ky1; ++ky)
-    for (int kx = kx0; kx <= kx1; ++kx) {
-      const float* wp = packed + ((size_t)(ky * 3 + kx) * Ip) * Op + n;
-      for (int cc = 0; cc < Cc; ++cc) acc += cvec[b * Cc + cc] * wp[(size_t)cc * Op];
-    }
+    for (int kx = kx0; kx <= kx1; ++kx) acc += taps[((size_t)b * 9 + ky * 3 + kx) * N + n];
   table[e] = acc;
 }
 
@@ -540,18 +558,26 @@ __global__ void border_sums_stage2(const float* __restrict__ tmp, int B, int S, 
       tapsum[((size_t)b * 9 + ky * 3 + kx) * C + c] = r;
     }
 }
-__global__ void cvec_dc_kernel(const float* __restrict__ packed, const float* __restrict__ tapsum, int B, int Cc, int Ip,
-                               int Op, int N, float* __restrict__ dc) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= B * Cc) return;
-  const int b = e / Cc, cc = e - b * Cc;
+// dc[b][cc] = sum_{t,n} P[t][cc][n] * tapsum[b][t][n]: block = 64 cc x 4 lanes over the 9*N products
+__global__ __launch_bounds__(256) void cvec_dc_kernel(const float* __restrict__ packed, const float* __restrict__ tapsum,
+                                                      int B, int Cc, int Ip, int Op, int N, float* __restrict__ dc) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, cl = threadIdx.x & 63, ln = threadIdx.x >> 6;
+  const int cc = blockIdx.y * 64 + cl;
   float acc = 0.f;
-  for (int t = 0; t < 9; ++t) {
-    const float* wp = packed + ((size_t)t * Ip + cc) * Op;
-    const float* sp = tapsum + ((size_t)b * 9 + t) * N;
-    for (int n = 0; n < N; ++n) acc += wp[n] * sp[n];
+  if (cc < Cc) {
+    for (int t = 0; t < 9; ++t) {
+      const float* wp = packed + ((size_t)t * Ip + cc) * Op;
+      const float* sp = tapsum + ((size_t)b * 9 + t) * N;
+      for (int n = ln * 4; n + 3 < N; n += 16) {
+        const f32x4 w4 = ld4(wp + n), s4 = ld4(sp + n);
+        acc += w4[0] * s4[0] + w4[1] * s4[1] + w4[2] * s4[2] + w4[3] * s4[3];
+      }
+    }
   }
-  dc[e] = acc;
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (ln == 0 && cc < Cc) dc[b * Cc + cc] = (sh[cl] + sh[64 + cl]) + (sh[128 + cl] + sh[192 + cl]);
 }
 __global__ void cvec_dw_kernel(const float* __restrict__ cvec, const float* __restrict__ tapsum, int B, int Cc, int N,
                                int O, int I_total, float* __restrict__ dw, int accumulate) {
@@ -816,7 +842,7 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
   S2I_REQUIRE(groups >= 1 && nparts % groups == 0, "bn finalize: %d partial rows do not split into %d groups", nparts,
               groups);
   const int ppg = nparts / groups;
-  if (ppg <= 64) {
+  if (ppg <= 8) {
     const int grid = (C + 255) / 256;
     if (mode == 0)
       hipLaunchKernelGGL((bn_finalize_small_kernel<0>), dim3(grid), dim3(256), 0, ST, part, ppg, groups, C, (double)count,
@@ -970,10 +996,14 @@ extern "C" int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, f
 }
 
 extern "C" int s2i_cvec_bias_table(const float* cvec, const float* packed, int B, int Cc, int Ip, int Op, int N,
-                                   float* table, void* stream) {
+                                   float* table, void* ws, size_t ws_bytes, void* stream) {
   S2I_REQUIRE(cvec && packed && table && B > 0 && Cc > 0 && Cc <= Ip && N > 0 && N <= Op, "cvec_bias_table: bad args");
-  hipLaunchKernelGGL(cvec_bias_table_kernel, dim3((B * 9 * N + 255) / 256), dim3(256), 0, ST, cvec, packed, B, Cc, Ip,
-                     Op, N, table);
+  S2I_REQUIRE(ws && ws_bytes >= (size_t)B * 9 * N * sizeof(float), "cvec_bias_table: workspace too small");
+  hipLaunchKernelGGL(cvec_tap_table_kernel, dim3(B * 9), dim3(256), Cc * sizeof(float), ST, cvec, packed, Cc, Ip, Op, N,
+                     (float*)ws);
+  S2I_LAUNCH_CHECK("cvec_tap_table");
+  hipLaunchKernelGGL(cvec_bias_table_kernel, dim3((B * 9 * N + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, N,
+                     table);
   S2I_LAUNCH_CHECK("cvec_bias_table");
   return 0;
 }
@@ -1004,8 +1034,8 @@ extern "C" int s2i_cvec_grads(const float* cvec, const float* packed, const floa
   S2I_REQUIRE(cvec && packed && tapsum && B > 0 && Cc > 0 && Cc <= Ip && N > 0 && N <= Op && O <= N && I_total >= Cc,
               "cvec_grads: bad args");
   if (dc) {
-    hipLaunchKernelGGL(cvec_dc_kernel, dim3((B * Cc + 255) / 256), dim3(256), 0, ST, packed, tapsum, B, Cc, Ip, Op, N,
-                       dc);
+    S2I_REQUIRE(N % 4 == 0 && Op % 4 == 0, "cvec_grads: N must be a multiple of 4");
+    hipLaunchKernelGGL(cvec_dc_kernel, dim3(B, (Cc + 63) / 64), dim3(256), 0, ST, packed, tapsum, B, Cc, Ip, Op, N, dc);
     S2I_LAUNCH_CHECK("cvec_dc");
   }
   if (dw_oihw) {

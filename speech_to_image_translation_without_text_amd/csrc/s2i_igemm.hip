@@ -67,12 +67,12 @@ __device__ __forceinline__ int tap_weight(int kind, int flip, int T, int t, int 
   return flip ? (T - 1 - t) : t;
 }
 
-template <int TM, int TN, int LDA, int LDB>
+template <int TM, int TN, int LDA, int LDB, int KK0 = 0, int KK1 = 16>
 __device__ __forceinline__ void mma_chunk(const float* As, const float* Bs, int arow0, int bcol0,
                                           int lane, f32x16 (&acc)[TM][TN]) {
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int kk = 0; kk < 16; ++kk) {
+  for (int kk = KK0; kk < KK1; ++kk) {
     const int k = 2 * kk + lh;
     float a[TM], b[TN];
 #pragma unroll
@@ -96,6 +96,9 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) 
 
 // CA32: gathered channel count (and the broadcast-vector part of it) is a multiple of 32, so a 32-deep K
 // chunk lies inside ONE tap (and entirely in x or entirely in cvec): the tap decode is scalar work.
+// Measured alternatives that lost (MI355X, 64->128 k4s2 on 24x128x128): two LDS stages with one barrier per
+// chunk (2 blocks/CU: 79 vs 98 TFLOP/s), a start-up stagger of the blocks (no change).  Three resident blocks
+// per CU with the plain two-barrier loop is the fastest structure found for v_mfma_f32_32x32x2_f32.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT, bool CA32>
 __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
@@ -239,26 +242,31 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
 
   const int c_begin = split * p.cps;
   const int c_end = min(p.nchunks, c_begin + p.cps);
-  if (c_begin < c_end) fetch(c_begin);
-  for (int kc = c_begin; kc < c_end; ++kc) {
+  auto stage_store = [&](float* Asd, float* Bsd) {
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) As[(kq * 4 + j) * LDA + mrow + 32 * i] = ra[i][j];
+      for (int j = 0; j < 4; ++j) Asd[(kq * 4 + j) * LDA + mrow + 32 * i] = ra[i][j];
     if (WT) {
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) Bs[(kq * 4 + j) * LDB + mrow + 32 * i] = rb[i][j];
+        for (int j = 0; j < 4; ++j) Bsd[(kq * 4 + j) * LDB + mrow + 32 * i] = rb[i][j];
     } else {
 #pragma unroll
       for (int q = 0; q < BSLOTS; ++q)
-        *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS_PER_PASS) * LDB + bcol4 * 4) = rb[q];
+        *reinterpret_cast<f32x4*>(Bsd + (brow + q * BROWS_PER_PASS) * LDB + bcol4 * 4) = rb[q];
     }
-    __syncthreads();
-    if (kc + 1 < c_end) fetch(kc + 1);
-    mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
-    __syncthreads();
+  };
+  {
+    if (c_begin < c_end) fetch(c_begin);
+    for (int kc = c_begin; kc < c_end; ++kc) {
+      stage_store(As, Bs);
+      __syncthreads();
+      if (kc + 1 < c_end) fetch(kc + 1);
+      mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue ----

@@ -282,8 +282,9 @@ class ConvBnAct(torch.autograd.Function):
             B, Cc = cvec.shape
             Ip, Op = packed.shape[1], packed.shape[2]
             table = torch.empty((B, 9, Cout), dtype=torch.float32, device=x.device)
-            check(lib.s2i_cvec_bias_table(ptr(cvec), ptr(packed), B, Cc, Ip, Op, Cout, ptr(table), stream()),
-                  "s2i_cvec_bias_table")
+            ws = _ws.get(B * 9 * Cout * 4, x.device)
+            check(lib.s2i_cvec_bias_table(ptr(cvec), ptr(packed), B, Cc, Ip, Op, Cout, ptr(table), ptr(ws),
+                                          ws.numel() * 4, stream()), "s2i_cvec_bias_table")
             y, part, nparts = conv_raw(kind, x, None, packed, Cout, wR=Ip, ldw=Op, stats=training, groups=groups,
                                        w_offset=Cc * Op, cls_bias=table)
         else:

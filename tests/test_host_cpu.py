@@ -1,0 +1,101 @@
+"""CPU suite for the host side: the C-ABI library loads and exports every symbol include/s2i_hip.h declares,
+the config surface behaves like the reference's (miscc/config.py:72-111), module / checkpoint layout, flat
+parameter storage.  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from speech_to_image_translation_without_text_amd import _lib
+    header = open(os.path.join(ROOT, "include", "s2i_hip.h")).read()
+    declared = set(re.findall(r"\b(s2i_[a-z0-9_]+)\s*\(", header))
+    declared -= {"s2i_conv_desc", "s2i_wgrad_desc"}
+    lib = _lib.load()
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, "declared in s2i_hip.h but not exported: %s" % missing
+    unbound = sorted(declared - set(_lib.EXPORTED_SYMBOLS))
+    assert not unbound, "declared in s2i_hip.h but not bound in _lib.py: %s" % unbound
+    assert lib.s2i_version() == 1
+
+
+def test_descriptor_validation_reports_errors_without_a_gpu():
+    """Planning functions are host code: bad shapes come back as an error string, not a crash."""
+    import ctypes
+    from speech_to_image_translation_without_text_amd import _lib
+    lib = _lib.load()
+    bad = _lib.ConvDesc(_lib.CONV_K3S1, 2, 6, 6, 8, 0, 16, 0, 0, 8, 16, 0, 0, 16, 1, 0)  # 6x6 is not a power of two
+    assert lib.s2i_conv_stat_parts(ctypes.byref(bad)) == -1
+    assert b"powers of two" in lib.s2i_last_error()
+    odd = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 6, 0, 16, 0, 0, 6, 16, 0, 0, 16, 1, 0)  # 6 channels
+    assert lib.s2i_conv_stat_parts(ctypes.byref(odd)) == -1
+    assert b"multiples of 4" in lib.s2i_last_error()
+    ok = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 8, 0, 16, 0, 0, 8, 16, 0, 1, 16, 1, 0)
+    assert lib.s2i_conv_stat_parts(ctypes.byref(ok)) == 1
+
+
+def test_no_cpu_fallback():
+    from speech_to_image_translation_without_text_amd import _lib, model
+    from helpers import CASES, configure
+    configure(CASES['small3'])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = model.G_NET()
+    with pytest.raises(_lib.S2IError):
+        g(torch.randn(2, 12), torch.randn(2, 32))
+
+
+def test_config_merge_rules(tmp_path):
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file, cfg_reset
+    cfg_reset()
+    good = tmp_path / "good.yml"
+    good.write_text("TREE:\n  BRANCH_NUM: 2\nTRAIN:\n  BATCH_SIZE: 8\n  COEFF:\n    UNCOND_LOSS: 1.0\n")
+    cfg_from_file(str(good))
+    assert cfg.TREE.BRANCH_NUM == 2 and cfg.TRAIN.BATCH_SIZE == 8 and cfg.TRAIN.COEFF.UNCOND_LOSS == 1.0
+    unknown = tmp_path / "unknown.yml"
+    unknown.write_text("NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        cfg_from_file(str(unknown))
+    wrong_type = tmp_path / "type.yml"
+    wrong_type.write_text("TRAIN:\n  BATCH_SIZE: 'eight'\n")
+    with pytest.raises(ValueError):
+        cfg_from_file(str(wrong_type))
+    cfg_reset()
+    cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
+    assert cfg.TRAIN.BATCH_SIZE == 24 and cfg.GAN.R_NUM == 2 and cfg.TRAIN.COEFF.CAL_LOSS == 50.0
+    cfg_reset()
+
+
+def test_wrapper_state_dict_has_module_prefix_and_flat_storage():
+    from helpers import CASES, build_nets
+    from speech_to_image_translation_without_text_amd import trainer as T
+    netG, netsD = build_nets(CASES['small3'])
+    wrapped = T._Replica(netsD[0], [0])
+    keys = list(wrapped.state_dict().keys())
+    assert keys[0] == 'module.img_code_s16.0.weight' and all(k.startswith('module.') for k in keys)
+    before = {k: v.clone() for k, v in netG.state_dict().items()}
+    flat = T.FlatNet(netG, 2e-4, with_ema=True)
+    for k, v in netG.state_dict().items():
+        assert torch.equal(v, before[k]), k          # re-homing keeps every value
+    for p, o, n in zip(flat.params, flat.offsets, flat.sizes):
+        assert o % 4 == 0 and p.data_ptr() == flat.p.data_ptr() + 4 * o and p.grad.data_ptr() == flat.g.data_ptr() + 4 * o
+    assert sum(flat.sizes) == sum(p.numel() for p in netG.parameters())
+    assert torch.equal(flat.avg, flat.p)
+
+
+def test_weights_init_matches_reference_rules():
+    from speech_to_image_translation_without_text_amd import trainer as T
+    conv = torch.nn.Conv2d(8, 16, 3)
+    bn = torch.nn.BatchNorm2d(16)
+    lin = torch.nn.Linear(12, 6)
+    torch.manual_seed(0)
+    for m in (conv, bn, lin):
+        T.weights_init(m)
+    w = conv.weight.view(16, -1)
+    assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-5)          # orthogonal rows
+    assert float(bn.bias.abs().max()) == 0.0 and abs(float(bn.weight.mean()) - 1.0) < 0.05
+    assert float(lin.bias.abs().max()) == 0.0
