@@ -73,7 +73,11 @@ def dominant_kernel_roofline(dev, B):
     ms = e0.elapsed_time(e1) / reps
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_F32_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_F32_TFLOPS, 4),
+            # HBM bytes per launch from rocprofv3 PMC passes of `bench.py --roofline-only`
+            # ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction; profiles/r01_roofline_dominant_kernel.md);
+            # not collected live, valid for the default batch 24 only
+            "traffic": 385.0e6 if B == 24 else None,
             "kernel": "igemm_fwd_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32)",
             "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) NHWC, %.2f GFLOP/launch, %.3f ms" % (B, flops / 1e9, ms)}
 
