@@ -421,6 +421,19 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int lds, floa
   }
 }
 
+__global__ void image_to_u8_kernel(const float* __restrict__ src, int lds, unsigned char* __restrict__ dst,
+                                   long long npix) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < npix;
+       e += (long long)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = ((src[e * lds + c] + 1.f) / 2.f) * 255.f;
+      v = fminf(fmaxf(v, 0.f), 255.f);
+      dst[e * 3 + c] = (unsigned char)v;  // .byte(): truncation
+    }
+  }
+}
+
 // per-image column sums, two stages: [B][S][C] partials then the S-sum
 __global__ __launch_bounds__(256) void spatial_sum_stage1(const float* __restrict__ src, int ld, int HW, int C,
                                                           int S, float* __restrict__ tmp, int cpb) {
@@ -969,6 +982,13 @@ extern "C" int s2i_nhwc_to_nchw(const float* src, int lds, float* dst, int B, in
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, ST, src, lds, dst,
                      B, C, H * W);
   S2I_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+
+extern "C" int s2i_image_to_u8(const float* src, int lds, unsigned char* dst, long long npix, void* stream) {
+  S2I_REQUIRE(src && dst && lds >= 3 && npix > 0, "image_to_u8: bad args");
+  hipLaunchKernelGGL(image_to_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, ST, src, lds, dst, npix);
+  S2I_LAUNCH_CHECK("image_to_u8");
   return 0;
 }
 

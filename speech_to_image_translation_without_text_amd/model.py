@@ -226,9 +226,9 @@ class GET_IMAGE_G(nn.Module):
         self.gf_dim = ngf
         self.img = nn.Sequential(conv3x3(ngf, 3), nn.Tanh())
 
-    def forward(self, h_code):
+    def forward(self, h_code, nhwc=False):
         img4 = ops.ConvAct.apply(h_code, self.img[0].weight, None, "k3s1", ACT_TANH, 4)
-        return ops.ToNCHW.apply(img4, 3)
+        return img4 if nhwc else ops.ToNCHW.apply(img4, 3)
 
 
 class G_NET(nn.Module):
@@ -256,9 +256,10 @@ class G_NET(nn.Module):
             self.h_net4 = NEXT_STAGE_G(self.gf_dim // 8, num_residual=1)
             self.img_net4 = GET_IMAGE_G(self.gf_dim // 16)
 
-    def forward(self, z_code, text_embedding=None, eps=None):
+    def forward(self, z_code, text_embedding=None, eps=None, nhwc=False):
         """z_code (B, Z_DIM), text_embedding (B, TEXT.DIMENSION) -> ([images NCHW], mu, logvar).
-        `eps` optionally pins the reparameterisation noise (parity tests); default: torch's RNG."""
+        `eps` optionally pins the reparameterisation noise (parity tests); default: torch's RNG.
+        `nhwc=True` (evaluation path) returns the images in the kernels' own NHWC4 layout."""
         if self.b_condition and text_embedding is not None:
             c_code, mu, logvar = self.ca_net(text_embedding, eps)
         else:
@@ -268,7 +269,7 @@ class G_NET(nn.Module):
         for i in range(min(self.branch_num, 4)):
             h_net = getattr(self, 'h_net%d' % (i + 1))
             h = h_net(z_code, c_code) if i == 0 else h_net(h, c_code)
-            fake_imgs.append(getattr(self, 'img_net%d' % (i + 1))(h))
+            fake_imgs.append(getattr(self, 'img_net%d' % (i + 1))(h, nhwc))
         return fake_imgs, mu, logvar
 
 

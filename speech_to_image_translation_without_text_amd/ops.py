@@ -653,3 +653,15 @@ def increment(counter):
 def scale_(t, a):
     lib = _lib_ready()
     check(lib.s2i_axpby(ptr(t), ptr(t), t.numel(), a, 0.0, stream()), "s2i_axpby")
+
+
+# ---- evaluation output ---------------------------------------------------------------------------------------------
+def images_to_uint8_hwc(img_nhwc):
+    """(B,H,W,C>=3) float NHWC in [-1,1] -> (B,H,W,3) uint8: the reference's save_singleimages conversion
+    (trainer.py:676-677) in one kernel, already in the HWC order a PNG encoder wants."""
+    lib = _lib_ready()
+    t, ld = _rows_view(img_nhwc)
+    B, H, W, _ = img_nhwc.shape
+    out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=img_nhwc.device)
+    check(lib.s2i_image_to_u8(ptr(t), ld, ptr(out), B * H * W, stream()), "s2i_image_to_u8")
+    return out

@@ -392,3 +392,47 @@ class condGANTrainer(object):
         save_model(self.netG, self.avg_param_G, self.netsD, count, self.model_dir)
         self.flatG.p.copy_(live)
         ops.refresh_packed(self.flatG.params)
+
+    # -- evaluation (trainer.py:664-679, 681-803): images only; the Inception metrics are short-circuited upstream too
+    def save_singleimages(self, images_u8, filenames, save_dir, split_dir, sentenceID, imsize, sample_idx=0):
+        """images_u8: (B,H,W,3) uint8 on the host.  Same file naming as the reference."""
+        from PIL import Image
+        for i in range(images_u8.shape[0]):
+            s_tmp = '%s/single_samples/%s/%s' % (save_dir, split_dir, filenames[i])
+            folder = s_tmp[:s_tmp.rfind('/')]
+            if not os.path.isdir(folder):
+                mkdir_p(folder)
+            Image.fromarray(images_u8[i]).save('%s_%d_sentence%d_%d.png' % (s_tmp, imsize, sentenceID, sample_idx))
+
+    @torch.no_grad()
+    def evaluate(self, split_dir):
+        """G in eval mode over every embedding of every test item -> PNGs under <NET_G dir>/iteration<N>/.
+        BatchNorm uses the running statistics (no batch barrier); the [-1,1] -> uint8 HWC conversion is one
+        kernel on the NHWC output.  Returns the reference's placeholder metrics (trainer.py:803)."""
+        if cfg.TRAIN.NET_G == '':
+            print('Error: the path for morels is not found!')
+            return None
+        if split_dir == 'test':
+            split_dir = 'valid'
+        dev = torch.device('cuda', self.gpus[0])
+        netG = G_NET()
+        netG.apply(weights_init)
+        netG = _Replica(netG.to(dev), self.gpus)
+        netG.load_state_dict(torch.load(cfg.TRAIN.NET_G, map_location='cpu', weights_only=True))
+        s_tmp = cfg.TRAIN.NET_G
+        iteration = int(s_tmp[s_tmp.rfind('_') + 1:s_tmp.rfind('.')])
+        save_dir = '%s/iteration%d' % (s_tmp[:s_tmp.rfind('/')], iteration)
+        netG.eval()
+        nz = cfg.GAN.Z_DIM
+        imsize = cfg.TREE.BASE_SIZE * (2 ** (cfg.TREE.BRANCH_NUM - 1))
+        for data in self.data_loader:
+            imgs, t_embeddings, filenames = data
+            t_embeddings = t_embeddings.float().to(dev)
+            batch_size = t_embeddings.shape[0]
+            noise = torch.empty(batch_size, nz, device=dev)
+            for i in range(t_embeddings.size(1)):
+                noise.normal_(0, 1)
+                fake_imgs, _, _ = netG.module(noise, t_embeddings[:, i, :].contiguous(), None, True)
+                u8 = ops.images_to_uint8_hwc(fake_imgs[-1]).cpu().numpy()
+                self.save_singleimages(u8, filenames, save_dir, split_dir, i, imsize, 0)
+        return [{'mu': 0, 'sigma': 0}, {'mu': 0, 'sigma': 0}]

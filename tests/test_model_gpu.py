@@ -304,3 +304,46 @@ def test_cpu_tensors_are_rejected():
     from speech_to_image_translation_without_text_amd import _lib, ops
     with pytest.raises(_lib.S2IError):
         ops.Glu2d.apply(torch.randn(2, 8))
+
+
+def test_evaluate_writes_reference_named_pngs(gpu, tmp_path):
+    """Evaluation path: checkpoint -> G.eval() -> uint8 PNGs with the reference's naming,
+    pixel values equal to the oracle's eval-mode images through the reference's conversion (within 1 level)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
+    case = CASES['small3']
+    netG, _ = build_nets(case)
+    model_dir = tmp_path / "Model"
+    model_dir.mkdir()
+    sd = {'module.' + k: v.clone() for k, v in netG.state_dict().items()}
+    torch.save(sd, str(model_dir / "netG_12.pth"))
+    cfg.TRAIN.NET_G = str(model_dir / "netG_12.pth")
+    cfg.TRAIN.FLAG = False
+    B, n_emb = 3, 2
+    g = torch.Generator().manual_seed(5)
+    emb = torch.randn(B, n_emb, case['t'], generator=g)
+    loader = [([torch.zeros(B, 3, 64, 64)], emb, ['birdA/img1', 'birdA/img2', 'birdB/img3'])]
+    tr = T.condGANTrainer(str(tmp_path / "out"), loader, 256, False)
+    torch.manual_seed(77)
+    tr.evaluate('test')
+    # replay the same device noise stream
+    torch.manual_seed(77)
+    noise = torch.empty(B, case['z'], device=gpu)
+    for i in range(n_emb):
+        noise.normal_(0, 1)
+        eps = torch.empty(B, case['ef'], device=gpu).normal_()  # CA_NET samples even in eval mode (model.py:188-195)
+        with torch.no_grad():
+            ofakes, _, _ = orc.g_forward({k: v.clone() for k, v in netG.state_dict().items()}, noise.cpu(), emb[:, i],
+                                         eps.cpu(), oracle_dims(case), training=False)
+        want = ofakes[-1].add(1).div(2).mul(255).clamp(0, 255).byte().permute(0, 2, 3, 1).numpy()
+        for b, name in enumerate(['birdA/img1', 'birdA/img2', 'birdB/img3']):
+            path = model_dir / "iteration12" / "single_samples" / "valid" / ("%s_256_sentence%d_0.png" % (name, i))
+            assert path.exists(), path
+            got = np.asarray(Image.open(str(path)))
+            assert got.shape == (256, 256, 3)
+            assert int(np.abs(got.astype(np.int32) - want[b].astype(np.int32)).max()) <= 1
+    cfg.TRAIN.NET_G = ''
+    cfg.TRAIN.FLAG = True
