@@ -347,3 +347,37 @@ def test_evaluate_writes_reference_named_pngs(gpu, tmp_path):
             assert int(np.abs(got.astype(np.int32) - want[b].astype(np.int32)).max()) <= 1
     cfg.TRAIN.NET_G = ''
     cfg.TRAIN.FLAG = True
+
+
+def test_full_size_config2_step_against_oracle(gpu):
+    """BASELINE config 2 at its FULL size (branch_num=3, 64/128/256 px, full width, batch 24, stacked D passes,
+    folded c_code): one complete iteration against the CPU oracle on the same seeded inputs."""
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import trainer as T
+    case = dict(CASES['full3_fwd'], B=24)
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    ostate = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    oout = orc.train_step(ostate, batch, oracle_dims(case))
+    netG.to(gpu)
+    for d in netsD:
+        d.to(gpu)
+    tr = T.condGANTrainer(None, None, 256, False)
+    tr.build(netG, netsD)
+    b = to_dev(batch, gpu)
+    errD, errG, kl = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'],
+                                   b['noise'], b['eps'])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert_close(tr.fake_imgs[i], oout['fake'][i], rtol=1e-3, atol=1e-4, what="img%d" % (64 << i))
+    assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total")
+    assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total")
+    assert_close(float(kl), oout['kl'], rtol=1e-3, atol=1e-5, what="kl")
+    # running statistics of the last D block after its four forwards, and the EMA shadow of G
+    sd = netsD[2].state_dict()
+    assert int(sd['img_code_s64_2.1.num_batches_tracked']) == 4
+    assert_close(sd['img_code_s64_2.1.running_mean'], ostate.ds[2]['img_code_s64_2.1.running_mean'], rtol=1e-3,
+                 atol=3e-4, what="D256 running_mean")
+    k0 = 'ca_net.fc.weight'
+    assert_close(tr.avg_param_G[0], ostate.avg_g[k0], rtol=1e-3, atol=1e-6, what="EMA")
