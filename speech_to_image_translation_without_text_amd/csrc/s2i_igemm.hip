@@ -56,6 +56,22 @@ __device__ __forceinline__ void tap_delta(int kind, int kw, int t, int py, int p
   }
 }
 
+// bit t set <=> tap t of the pixel whose base coordinate is (by,bx) falls inside the H x W tensor
+__device__ __forceinline__ unsigned tap_mask(int kind, int kw, int by, int bx, int H, int W, int py, int px) {
+  if (kind == S2I_TCONV_K4S2) {
+    const int sy = py ? 1 : -1, sx = px ? 1 : -1;
+    const bool y0 = by >= 0 && by < H, y1 = by + sy >= 0 && by + sy < H;
+    const bool x0 = bx >= 0 && bx < W, x1 = bx + sx >= 0 && bx + sx < W;
+    return (unsigned)(y0 && x0) | ((unsigned)(y0 && x1) << 1) | ((unsigned)(y1 && x0) << 2) |
+           ((unsigned)(y1 && x1) << 3);
+  }
+  unsigned cols = 0, mask = 0;
+  for (int kx = 0; kx < kw; ++kx) cols |= (unsigned)(bx + kx >= 0 && bx + kx < W) << kx;
+  for (int ky = 0; ky < kw; ++ky)
+    if (by + ky >= 0 && by + ky < H) mask |= cols << (ky * kw);
+  return mask;
+}
+
 // which tap of the packed weight tensor the gather tap t multiplies
 __device__ __forceinline__ int tap_weight(int kind, int flip, int T, int t, int py, int px) {
   if (kind == S2I_TCONV_K4S2) {
@@ -140,12 +156,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
       const int r = m & ((1 << p.lgHoWo) - 1);
       const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
       const int by = oy * s - pad, bx = ox * s - pad;
-      for (int t = 0; t < p.T; ++t) {
-        int dy, dx;
-        tap_delta(p.kind, kw, t, py, px, dy, dx);
-        const int iy = by + dy, ix = bx + dx;
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) mask |= 1u << t;
-      }
+      mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
       base = (((b * p.H + by) * p.W + bx) * p.Cx + kq * 4) * 4;
       coff = (b * p.Cc + kq * 4) * 4;
     }

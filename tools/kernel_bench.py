@@ -19,6 +19,10 @@ CASES = [
     ("fwd k3s1 64->128 @64", CONV_K3S1, (B, 64, 64, 64), 128, 0, (9, 64, 128)),
     ("dgr k3s1 64<-128 @64", CONV_K3S1, (B, 64, 64, 128), 64, 1, (9, 64, 128)),
     ("fwd up 64->64 @64->128", TCONV_K4S2, (B, 64, 64, 64), 64, 0, (16, 64, 64)),
+    ("k1 overhead K=32", 0, (B, 64, 64, 32), 128, 0, (1, 32, 128)),
+    ("k1 K=64", 0, (B, 64, 64, 64), 128, 0, (1, 64, 128)),
+    ("k1 K=256", 0, (B, 64, 64, 256), 128, 0, (1, 256, 128)),
+    ("k1 K=1024", 0, (B, 64, 64, 1024), 128, 0, (1, 1024, 128)),
 ]
 which = sys.argv[1:] or None
 reps = int(os.environ.get("REPS", "20"))
@@ -27,7 +31,9 @@ for name, kind, xs, N, wmode, ps in CASES:
         continue
     x = torch.randn(xs, device=dev)
     packed = torch.randn(ps, device=dev) * 0.05
-    T = {CONV_K3S1: 9, CONV_K4S2: 16, TCONV_K4S2: 4}[kind]
+    if os.environ.get('ZERO') == '1':
+        x.zero_(); packed.zero_()
+    T = {0: 1, CONV_K3S1: 9, CONV_K4S2: 16, TCONV_K4S2: 4}[kind]
     Bx, H, W, Cx = xs
     Mout = Bx * H * W * (4 if kind == TCONV_K4S2 else 1) // (4 if kind == CONV_K4S2 else 1)
     flops = 2.0 * Mout * N * T * Cx
