@@ -32,6 +32,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-encoder", action="store_true",
+                    help="BASELINE config 5: run the speech-encoder front-end (CNN + BiLSTM, eval mode) on synthetic "
+                         "log-mel input inside every step and feed its output as the embedding")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel launches (the command profiled for profiles/*roofline*)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
@@ -154,9 +157,20 @@ def main():
     noise = torch.empty(B, cfg.GAN.Z_DIM, device=dev)
     eps = torch.empty(B, cfg.GAN.EMBEDDING_DIM, device=dev)
 
+    encoder = None
+    if args.with_encoder:
+        from speech_to_image_translation_without_text_amd.speech_encoder import CNNRNN
+        encoder = CNNRNN(40, embedding_dim=1024, nhidden=1024, nsent=1024, bidirectional=True, rnn_layers=1).to(dev).eval()
+        mel = torch.randn(B, 40, 2048, device=dev, generator=gen) * 20 - 40
+        n_frames = torch.sort(torch.randint(640, 2049, (B,), generator=torch.Generator().manual_seed(1 + rank)),
+                              descending=True)[0]
+        cap_lens = (n_frames // 64).tolist()
+
     def one_step():
         noise.normal_(generator=gen)
         eps.normal_(generator=gen)
+        if encoder is not None:
+            batch["emb"] = encoder.extract_feature(mel, cap_lens)
         emb = batch["emb"].detach().requires_grad_(True)
         return tr.train_step(batch["real"], batch["wrong"], emb, batch["labels"], noise, eps)
 
@@ -198,7 +212,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, fp32, "
                                    "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise" % B,
-                       "global_batch": B * world, "parallelism": "dp%d" % world},
+                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "speech_encoder_in_step": bool(args.with_encoder)},
             "step_roofline": {
                 "flops_frac": round(step_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
                 "achieved_tflops": round(step_flops / (ms * 1e-3) / 1e12, 2),

@@ -35,11 +35,16 @@ extern "C" {
 #define S2I_TCONV_K4S2   3  /* 4-phase transposed conv k4 s2 p1: nearest x2 + conv3x3 collapsed
                                (model.py:133-140) and dgrad of Conv2d(k4,s2,p1)                 */
 
+#define S2I_CONV_1D      4  /* (1 x kw) conv along W with stride / padding from the descriptor: the temporal
+                               convolutions of the speech encoder (Audio_to_Image/speech_encoder.py:26-37);
+                               forward only                                                      */
+
 /* activations */
 #define S2I_ACT_NONE     0
 #define S2I_ACT_GLU      1  /* model.py:112-122 */
 #define S2I_ACT_LRELU    2  /* nn.LeakyReLU(0.2), model.py:363, 373 */
 #define S2I_ACT_TANH     3  /* model.py:293 */
+#define S2I_ACT_RELU     4  /* speech_encoder.py:12 */
 
 /* weight pack modes */
 #define S2I_PACK_PLAIN   0  /* P[t][i][o] = W[o][i][t]                                          */
@@ -69,6 +74,7 @@ typedef struct s2i_conv_desc {
                     the batch axis (real / wrong / fake passes of trainer.py:390-392 in one launch);
                     statistics are kept per group.  0 or 1 = one batch                           */
   int nosplit;   /* 1: never split K (required with a class bias, s2i_conv_forward_cls)           */
+  int kw, stride, pad; /* S2I_CONV_1D geometry (ignored by the other kinds)                       */
 } s2i_conv_desc;
 
 /* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */
@@ -231,6 +237,22 @@ int s2i_bce_backward(const float* prob, float target, int B, float weight, const
    dscores = d loss / d S (so that dX = (dS + dS^T) X), both scaled by nothing: caller scales. */
 int s2i_cal_loss(const float* scores, const int* labels, int B, int D, float* loss, int accumulate,
                  float* dscores_sym, void* stream);
+
+/* ---- speech-encoder front-end (Audio_to_Image/speech_encoder.py:15-97), inference ---------------- */
+/* nn.MaxPool2d((1,3), stride (1,2), padding (0,1)) on NHWC [B][H][W][C] -> [B][H][W/2][C] */
+int s2i_maxpool_w3s2(const float* x, int B, int H, int W, int C, float* y, void* stream);
+/*
+ * One nn.LSTM step for every sequence of a packed batch, one direction.
+ *   xproj [B][T][ldx] (this direction's 4*Hd gate pre-activations from the input, biases included, at
+ *   column offset already applied), hproj [B][4*Hd] = h_prev W_hh^T, gates in torch order (i, f, g, o).
+ *   Sequence b has lens[b] valid steps; at step `s` it processes t = s (forward) or lens[b]-1-s (reverse);
+ *   finished sequences keep their state and write nothing (padded outputs stay zero).
+ *   h, c [B][Hd] are updated in place; out [B][T][ldo] receives h at (b, t) at column offset applied.
+ */
+int s2i_lstm_cell(const float* xproj, int ldx, const float* hproj, const int* lens, int B, int T, int Hd,
+                  int step, int reverse, float* h, float* c, float* out, int ldo, void* stream);
+/* y[b][c] = mean over the T rows of x[b][t][c] (sent_emb = output.mean(-2), speech_encoder.py:93) */
+int s2i_time_mean(const float* x, int B, int T, int C, float* y, void* stream);
 
 /* ---- optimiser (trainer.py:236-252, 571-572) -------------------------------------------------- */
 /* torch.optim.Adam (no weight decay, no amsgrad) on a flat buffer, step = 1-based step count */

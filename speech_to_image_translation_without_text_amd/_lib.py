@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libs2i_hip.so")
 
 # enums of include/s2i_hip.h
-CONV_K1, CONV_K3S1, CONV_K4S2, TCONV_K4S2 = 0, 1, 2, 3
-ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+CONV_K1, CONV_K3S1, CONV_K4S2, TCONV_K4S2, CONV_1D = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
 PACK_PLAIN, PACK_UPFOLD = 0, 1
 
 c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
@@ -23,7 +23,7 @@ c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Cx", "Cc", "N", "wmode", "flip", "wR",
-                                     "ldw", "act", "stats", "ldy", "groups", "nosplit")]
+                                     "ldw", "act", "stats", "ldy", "groups", "nosplit", "kw", "stride", "pad")]
 
 
 class WgradDesc(ctypes.Structure):
@@ -71,6 +71,9 @@ _SIGNATURES = {
     "s2i_bce_forward": (c_int, [P, c_float, c_int, c_float, P, c_int, P]),
     "s2i_bce_backward": (c_int, [P, c_float, c_int, c_float, P, P, P]),
     "s2i_cal_loss": (c_int, [P, P, c_int, c_int, P, c_int, P, P]),
+    "s2i_maxpool_w3s2": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    "s2i_lstm_cell": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "s2i_time_mean": (c_int, [P, c_int, c_int, c_int, P, P]),
     "s2i_adam_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "s2i_increment": (c_int, [P, P]),
     "s2i_ema_update": (c_int, [P, P, c_ll, c_float, P]),

@@ -771,6 +771,53 @@ __global__ __launch_bounds__(256) void cal_loss_kernel(const float* __restrict__
   }
 }
 
+// ---- speech-encoder front-end -------------------------------------------------------------------------
+__global__ void maxpool_w3s2_kernel(const float* __restrict__ x, int W, int C, long long total, float* __restrict__ y) {
+  const int Q = C / 4, Wo = W / 2;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % Q);
+    const long long r = e / Q;         // (b*H + h) * Wo + ox
+    const int ox = (int)(r % Wo);
+    const long long bh = r / Wo;
+    const float* row = x + bh * W * C + q * 4;
+    const int x0 = 2 * ox - 1;
+    f32x4 m = ld4(row + (long long)(x0 + 1) * C);  // centre tap is always in bounds
+    if (x0 >= 0) { const f32x4 v = ld4(row + (long long)x0 * C); for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]); }
+    if (x0 + 2 < W) { const f32x4 v = ld4(row + (long long)(x0 + 2) * C); for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]); }
+    st4(y + r * C + q * 4, m);
+  }
+}
+__global__ void lstm_cell_kernel(const float* __restrict__ xproj, int ldx, const float* __restrict__ hproj,
+                                 const int* __restrict__ lens, int B, int T, int Hd, int step, int reverse,
+                                 float* __restrict__ h, float* __restrict__ c, float* __restrict__ out, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * Hd) return;
+  const int b = e / Hd, j = e - b * Hd;
+  const int len = lens[b];
+  if (step >= len) return;
+  const int t = reverse ? len - 1 - step : step;
+  const float* xp = xproj + ((size_t)b * T + t) * ldx;
+  const float* hp = hproj + (size_t)b * 4 * Hd;
+  const float gi = sigmoidf_(xp[j] + hp[j]);
+  const float gf = sigmoidf_(xp[Hd + j] + hp[Hd + j]);
+  const float gg = tanhf(xp[2 * Hd + j] + hp[2 * Hd + j]);
+  const float go = sigmoidf_(xp[3 * Hd + j] + hp[3 * Hd + j]);
+  const float cn = gf * c[e] + gi * gg;
+  const float hn = go * tanhf(cn);
+  c[e] = cn;
+  h[e] = hn;
+  out[((size_t)b * T + t) * ldo + j] = hn;
+}
+__global__ void time_mean_kernel(const float* __restrict__ x, int B, int T, int C, float* __restrict__ y) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * C) return;
+  const int b = e / C, ch = e - b * C;
+  float acc = 0.f;
+  for (int t = 0; t < T; ++t) acc += x[((size_t)b * T + t) * C + ch];
+  y[e] = acc / (float)T;
+}
+
 // ---- optimiser ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n4,
@@ -1131,6 +1178,30 @@ extern "C" int s2i_cal_loss(const float* scores, const int* labels, int B, int D
   S2I_REQUIRE(scores && labels && loss && B > 0 && D > 0, "cal_loss: bad args");
   hipLaunchKernelGGL(cal_loss_kernel, dim3(1), dim3(256), 0, ST, scores, labels, B, D, loss, accumulate, dscores_sym);
   S2I_LAUNCH_CHECK("cal_loss");
+  return 0;
+}
+
+extern "C" int s2i_maxpool_w3s2(const float* x, int B, int H, int W, int C, float* y, void* stream) {
+  S2I_REQUIRE(x && y && B > 0 && H > 0 && W >= 2 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_w3s2: bad args");
+  const long long total = (long long)B * H * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_w3s2_kernel, dim3(grid_for(total)), dim3(256), 0, ST, x, W, C, total, y);
+  S2I_LAUNCH_CHECK("maxpool_w3s2");
+  return 0;
+}
+extern "C" int s2i_lstm_cell(const float* xproj, int ldx, const float* hproj, const int* lens, int B, int T, int Hd,
+                             int step, int reverse, float* h, float* c, float* out, int ldo, void* stream) {
+  S2I_REQUIRE(xproj && hproj && lens && h && c && out && B > 0 && T > 0 && Hd > 0 && step >= 0 && step < T,
+              "lstm_cell: bad args");
+  S2I_REQUIRE(ldx >= 4 * Hd && ldo >= Hd, "lstm_cell: row strides too small");
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3((B * Hd + 255) / 256), dim3(256), 0, ST, xproj, ldx, hproj, lens, B, T, Hd,
+                     step, reverse, h, c, out, ldo);
+  S2I_LAUNCH_CHECK("lstm_cell");
+  return 0;
+}
+extern "C" int s2i_time_mean(const float* x, int B, int T, int C, float* y, void* stream) {
+  S2I_REQUIRE(x && y && B > 0 && T > 0 && C > 0, "time_mean: bad args");
+  hipLaunchKernelGGL(time_mean_kernel, dim3((B * C + 255) / 256), dim3(256), 0, ST, x, B, T, C, y);
+  S2I_LAUNCH_CHECK("time_mean");
   return 0;
 }
 

@@ -35,12 +35,14 @@ struct IgemmP {
   int M, N, K, T;
   int kind, flip, act, stats, splitk, cps, nchunks;
   int ldw, wR, ldy, nparts;
+  int g_kw, g_s, g_pad;  // geometry of S2I_CONV_1D (1 x kw taps along W, stride, padding)
   unsigned x_bytes, c_bytes, w_bytes;
   long long Mrows;
 };
 
-__device__ __forceinline__ void geom(int kind, int& s, int& pad, int& kw) {
-  if (kind == S2I_CONV_K3S1) { s = 1; pad = 1; kw = 3; }
+__device__ __forceinline__ void geom(const IgemmP& p, int kind, int& s, int& pad, int& kw) {
+  if (kind == S2I_CONV_1D) { s = p.g_s; pad = p.g_pad; kw = p.g_kw; }
+  else if (kind == S2I_CONV_K3S1) { s = 1; pad = 1; kw = 3; }
   else if (kind == S2I_CONV_K4S2) { s = 2; pad = 1; kw = 4; }
   else { s = 1; pad = 0; kw = 1; }
 }
@@ -50,10 +52,19 @@ __device__ __forceinline__ void tap_delta(int kind, int kw, int t, int py, int p
     const int a = t >> 1, b = t & 1;
     dy = a ? (py ? 1 : -1) : 0;
     dx = b ? (px ? 1 : -1) : 0;
+  } else if (kind == S2I_CONV_1D) {
+    dy = 0;
+    dx = t;
   } else {
     dy = t / kw;
     dx = t - dy * kw;
   }
+}
+
+__device__ __forceinline__ void geom(int kind, int& s, int& pad, int& kw) {
+  if (kind == S2I_CONV_K3S1) { s = 1; pad = 1; kw = 3; }
+  else if (kind == S2I_CONV_K4S2) { s = 2; pad = 1; kw = 4; }
+  else { s = 1; pad = 0; kw = 1; }
 }
 
 // bit t set <=> tap t of the pixel whose base coordinate is (by,bx) falls inside the H x W tensor
@@ -67,6 +78,7 @@ __device__ __forceinline__ unsigned tap_mask(int kind, int kw, int by, int bx, i
   }
   unsigned cols = 0, mask = 0;
   for (int kx = 0; kx < kw; ++kx) cols |= (unsigned)(bx + kx >= 0 && bx + kx < W) << kx;
+  if (kind == S2I_CONV_1D) return (by >= 0 && by < H) ? cols : 0u;
   for (int ky = 0; ky < kw; ++ky)
     if (by + ky >= 0 && by + ky < H) mask |= cols << (ky * kw);
   return mask;
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int kq = tid & 7, mrow = tid >> 3;
   int s, pad, kw;
-  geom(p.kind, s, pad, kw);
+  geom(p, p.kind, s, pad, kw);
 
   // hardware-bounds-checked descriptors: an invalid element is fetched at S2I_OOB and reads as zero,
   // so the gather needs no exec-mask branches
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
       const int b = m >> p.lgHoWo;
       const int r = m & ((1 << p.lgHoWo) - 1);
       const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
-      const int by = oy * s - pad, bx = ox * s - pad;
+      const int by = p.kind == S2I_CONV_1D ? oy : oy * s - pad, bx = ox * s - pad;
       mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
       base = (((b * p.H + by) * p.W + bx) * p.Cx + kq * 4) * 4;
       coff = (b * p.Cc + kq * 4) * 4;
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
             if (p.bias) v += p.bias[n];
             if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
             else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+            else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
           }
           outp[row * ldo + n] = v;
         }
@@ -391,6 +404,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long
     if (bias) v += bias[n];
     if (act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
     else if (act == S2I_ACT_TANH) v = tanhf(v);
+    else if (act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
     y[row * ldy + n] = v;
   }
 }
@@ -673,6 +687,12 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
       S2I_REQUIRE(d->H >= 2 && d->W >= 2, "conv k4s2: extent < 2");
       pl->T = 16; pl->Ho = d->H / 2; pl->Wo = d->W / 2; break;
     case S2I_TCONV_K4S2: pl->T = 4; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
+    case S2I_CONV_1D:
+      S2I_REQUIRE(d->kw >= 1 && d->kw <= 31 && d->stride >= 1 && d->pad >= 0, "conv1d: bad kw/stride/pad");
+      S2I_REQUIRE(d->wmode == 0 && !d->flip, "conv1d: forward only");
+      pl->T = d->kw; pl->Ho = d->H; pl->Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+      S2I_REQUIRE(pl->Wo >= 1 && s2i_is_pow2(pl->Wo), "conv1d: output width %d is not a power of two", pl->Wo);
+      break;
     default: S2I_FAIL("conv: unknown kind %d", d->kind);
   }
   const long long M = (long long)d->B * pl->Ho * pl->Wo;
@@ -820,6 +840,7 @@ extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, cons
   p.kind = d->kind; p.flip = d->flip; p.act = d->act; p.stats = d->stats;
   p.splitk = pl.splitk; p.cps = pl.cps; p.nchunks = pl.nchunks;
   p.ldw = d->ldw; p.wR = d->wR; p.ldy = d->ldy; p.nparts = pl.gridM * pl.nphases;
+  p.g_kw = d->kw; p.g_s = d->stride; p.g_pad = d->pad;
   p.Mrows = pl.Mrows;
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   const bool wt = d->wmode != 0;

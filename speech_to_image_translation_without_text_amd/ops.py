@@ -130,7 +130,7 @@ def _geom(kind, H, W):
 
 
 def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1,
-             w_offset=0, cls_bias=None):
+             w_offset=0, cls_bias=None, conv1d=None):
     """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts).
     w_offset (floats) skips leading weight rows (the c_code rows of a jointConv); cls_bias [B][9][N]
     adds their pre-reduced contribution per border class."""
@@ -138,8 +138,11 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
     B, H, W, Cx = x.shape
     Cc = 0 if cvec is None else cvec.shape[1]
     Ho, Wo = _geom(kind, H, W)
+    kw1, st1, pd1 = conv1d if conv1d is not None else (0, 0, 0)
+    if conv1d is not None:
+        Ho, Wo = H, (W + 2 * pd1 - kw1) // st1 + 1
     d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
-                 1 if cls_bias is not None else 0)
+                 1 if cls_bias is not None else 0, kw1, st1, pd1)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
     part, nparts = None, 0
     if stats:
