@@ -231,6 +231,14 @@ int s2i_bce_forward(const float* prob, float target, int B, float weight, float*
 int s2i_bce_backward(const float* prob, float target, int B, float weight, const float* gout,
                      float* dprob, void* stream);
 
+/* Sum of G*H BCE terms in one launch (the six terms of trainer.py:394-409): probs[h] is head h's
+   probabilities for G stacked batches of B rows; term (g,h) uses target[g*H+h] and weight[g*H+h].
+   loss = sum_{g,h} weight * mean_b BCE(probs[h][g*B+b], target);  backward writes dprobs[h] likewise. */
+int s2i_bce_multi_forward(const float* const* probs_dev, const float* target, const float* weight, int G, int H,
+                          int B, float* loss, void* stream);
+int s2i_bce_multi_backward(const float* const* probs_dev, const float* target, const float* weight, int G, int H,
+                           int B, const float* gout, float* const* dprobs_dev, void* stream);
+
 /* ---- class-aware loss (trainer.py:298-311) ------------------------------------------------------ */
 /* scores = X X^T [B][B] (from s2i_conv_forward, K1, wmode 1); labels int32 [B];
    loss = max(0, mean(S) - mean(S[same class, off-diagonal])) / D, 0 when no such pair.

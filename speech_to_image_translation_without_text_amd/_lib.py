@@ -70,6 +70,8 @@ _SIGNATURES = {
     "s2i_logit_backward": (c_int, [P, P, P, P, c_int, c_int, P, c_int, P, P, c_int, P]),
     "s2i_bce_forward": (c_int, [P, c_float, c_int, c_float, P, c_int, P]),
     "s2i_bce_backward": (c_int, [P, c_float, c_int, c_float, P, P, P]),
+    "s2i_bce_multi_forward": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "s2i_bce_multi_backward": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
     "s2i_cal_loss": (c_int, [P, P, c_int, c_int, P, c_int, P, P]),
     "s2i_maxpool_w3s2": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "s2i_lstm_cell": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),

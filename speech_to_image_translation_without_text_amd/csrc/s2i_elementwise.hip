@@ -123,10 +123,11 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ out, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate, int qpb,
                                                            long long* __restrict__ nbt) {
-  extern __shared__ double shd[];  // [2][1024][4]
+  extern __shared__ double shd[];  // [2][blockDim.x][4]
   if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += G;  // num_batches_tracked
   const int tid = threadIdx.x;
-  const int lanes = 1024 / qpb;
+  const int NT = blockDim.x;
+  const int lanes = NT / qpb;
   const int ql = tid % qpb, pl = tid / qpb;
   const int quad = blockIdx.x * qpb + ql;
   const int Q = C / 4;
@@ -145,8 +146,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      shd[(0 * 1024 + tid) * 4 + j] = a0[j];
-      shd[(1 * 1024 + tid) * 4 + j] = a1[j];
+      shd[(0 * NT + tid) * 4 + j] = a0[j];
+      shd[(1 * NT + tid) * 4 + j] = a1[j];
     }
     __syncthreads();
     // tree over the part lanes (thread tid = pl * qpb + ql; lanes is a power of two)
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
       if (pl < sft) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          shd[(0 * 1024 + tid) * 4 + j] += shd[(0 * 1024 + tid + sft * qpb) * 4 + j];
-          shd[(1 * 1024 + tid) * 4 + j] += shd[(1 * 1024 + tid + sft * qpb) * 4 + j];
+          shd[(0 * NT + tid) * 4 + j] += shd[(0 * NT + tid + sft * qpb) * 4 + j];
+          shd[(1 * NT + tid) * 4 + j] += shd[(1 * NT + tid + sft * qpb) * 4 + j];
         }
       }
       __syncthreads();
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     if (pl == 0 && quad < Q) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        a0[j] = shd[(0 * 1024 + tid) * 4 + j];
-        a1[j] = shd[(1 * 1024 + tid) * 4 + j];
+        a0[j] = shd[(0 * NT + tid) * 4 + j];
+        a1[j] = shd[(1 * NT + tid) * 4 + j];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -728,6 +729,39 @@ __global__ void bce_bwd_kernel(const float* __restrict__ prob, float target, int
   dprob[b] = weight * gout[0] * (p - target) / den / (float)B;
 }
 
+// all BCE terms of one discriminator update: H heads x G stacked batches (pointers passed by value)
+struct MultiPtr { const float* p[4]; float* d[4]; };
+__global__ __launch_bounds__(256) void bce_multi_fwd_kernel(MultiPtr mp, const float* __restrict__ target,
+                                                            const float* __restrict__ weight, int G, int H, int B,
+                                                            float* __restrict__ loss) {
+  __shared__ float sh[256];
+  float acc = 0.f;
+  const int n = G * H * B;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int b = e % B, gh = e / B, h = gh % H, g = gh / H;
+    const float p = mp.p[h][g * B + b];
+    const float t = target[g * H + h];
+    const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+    acc += weight[g * H + h] * -(t * lp + (1.f - t) * lq);
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = sh[0] / (float)B;
+}
+__global__ void bce_multi_bwd_kernel(MultiPtr mp, const float* __restrict__ target, const float* __restrict__ weight,
+                                     int G, int H, int B, const float* __restrict__ gout) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= G * H * B) return;
+  const int b = e % B, gh = e / B, h = gh % H, g = gh / H;
+  const float p = mp.p[h][g * B + b];
+  const float den = fmaxf((1.f - p) * p, 1e-12f);
+  mp.d[h][g * B + b] = weight[g * H + h] * gout[0] * (p - target[g * H + h]) / den / (float)B;
+}
+
 // ---- class-aware loss ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cal_loss_kernel(const float* __restrict__ S, const int* __restrict__ labels,
                                                        int B, int D, float* __restrict__ loss, int accumulate,
@@ -918,12 +952,16 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
   int qpb = 1;
   while (qpb < 32 && qpb * 32 < Q) qpb <<= 1;
   const int grid = (Q + qpb - 1) / qpb;
-  const size_t shbytes = 2 * 1024 * 4 * sizeof(double);
+  // part lanes: no more than the list is long (power of two), at most 1024 threads per block
+  int lanes = 1;
+  while (lanes < ppg && lanes * qpb < 1024) lanes <<= 1;
+  const int nthreads = qpb * lanes;
+  const size_t shbytes = (size_t)2 * nthreads * 4 * sizeof(double);
   if (mode == 0)
-    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(1024), shbytes, ST, part, ppg, groups, C, (double)count,
+    hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(nthreads), shbytes, ST, part, ppg, groups, C, (double)count,
                        gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   else
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(1024), shbytes, ST, part, ppg, groups, C, (double)count,
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(nthreads), shbytes, ST, part, ppg, groups, C, (double)count,
                        gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
   S2I_LAUNCH_CHECK("bn_finalize");
   return 0;
@@ -1170,6 +1208,31 @@ extern "C" int s2i_bce_backward(const float* prob, float target, int B, float we
   S2I_REQUIRE(prob && gout && dprob && B > 0, "bce_backward: bad args");
   hipLaunchKernelGGL(bce_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, ST, prob, target, B, weight, gout, dprob);
   S2I_LAUNCH_CHECK("bce_backward");
+  return 0;
+}
+
+extern "C" int s2i_bce_multi_forward(const float* const* probs, const float* target, const float* weight, int G, int H,
+                                     int B, float* loss, void* stream) {
+  S2I_REQUIRE(probs && target && weight && loss && G > 0 && H > 0 && H <= 4 && B > 0, "bce_multi_forward: bad args");
+  MultiPtr mp = {};
+  for (int h = 0; h < H; ++h) { S2I_REQUIRE(probs[h], "bce_multi_forward: null head"); mp.p[h] = probs[h]; }
+  hipLaunchKernelGGL(bce_multi_fwd_kernel, dim3(1), dim3(256), 0, ST, mp, target, weight, G, H, B, loss);
+  S2I_LAUNCH_CHECK("bce_multi_forward");
+  return 0;
+}
+extern "C" int s2i_bce_multi_backward(const float* const* probs, const float* target, const float* weight, int G, int H,
+                                      int B, const float* gout, float* const* dprobs, void* stream) {
+  S2I_REQUIRE(probs && dprobs && target && weight && gout && G > 0 && H > 0 && H <= 4 && B > 0,
+              "bce_multi_backward: bad args");
+  MultiPtr mp = {};
+  for (int h = 0; h < H; ++h) {
+    S2I_REQUIRE(probs[h] && dprobs[h], "bce_multi_backward: null head");
+    mp.p[h] = probs[h];
+    mp.d[h] = dprobs[h];
+  }
+  hipLaunchKernelGGL(bce_multi_bwd_kernel, dim3((G * H * B + 255) / 256), dim3(256), 0, ST, mp, target, weight, G, H, B,
+                     gout);
+  S2I_LAUNCH_CHECK("bce_multi_backward");
   return 0;
 }
 

@@ -919,6 +919,8 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     while (RT > 1 && (long long)s2i_cdiv(ncols, 32) * s2i_cdiv(nrows, RT) < 128) RT >>= 1;
     dim3 fgrid(s2i_cdiv(ncols, 32), s2i_cdiv(nrows, RT));
     const size_t shb = (size_t)pl.T * RT * 33 * sizeof(float);
+    // two passes (measured: 27 + 17 us against 53 us for one pass that walks the slabs tile by tile): first a
+    // float4 stream folds the split slabs into slab 0, then the tile kernel transposes slab 0 into OIHW
     int S = pl.splitk;
     const long long kn = (long long)pl.K * d->N;
     if (S > 2 && (kn % 4) == 0) {

@@ -557,6 +557,40 @@ class BCELoss(torch.autograd.Function):
         return dprob, None, None
 
 
+class BCEMulti(torch.autograd.Function):
+    """All BCE terms of one discriminator update in one launch: `heads` = H probability vectors of G stacked
+    batches (G*B rows each); term (g, h) has target targets[g][h] and weight weights[g][h]
+    (trainer.py:394-409 sums six of them)."""
+
+    @staticmethod
+    def forward(ctx, targets_dev, weights_dev, G, *heads):
+        lib = _lib_ready()
+        heads = [h.contiguous() for h in heads]
+        H = len(heads)
+        B = heads[0].numel() // G
+        arr = (ctypes.c_void_p * H)(*[ptr(h) for h in heads])
+        loss = torch.empty((), dtype=torch.float32, device=heads[0].device)
+        check(lib.s2i_bce_multi_forward(arr, ptr(targets_dev), ptr(weights_dev), G, H, B, ptr(loss), stream()),
+              "s2i_bce_multi_forward")
+        ctx.save_for_backward(targets_dev, weights_dev, *heads)
+        ctx.G = G
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib_ready()
+        targets_dev, weights_dev = ctx.saved_tensors[:2]
+        heads = ctx.saved_tensors[2:]
+        H, G = len(heads), ctx.G
+        B = heads[0].numel() // G
+        grads = [torch.empty_like(h) for h in heads]
+        pin = (ctypes.c_void_p * H)(*[ptr(h) for h in heads])
+        pout = (ctypes.c_void_p * H)(*[ptr(t) for t in grads])
+        check(lib.s2i_bce_multi_backward(pin, ptr(targets_dev), ptr(weights_dev), G, H, B, ptr(g.contiguous()), pout,
+                                         stream()), "s2i_bce_multi_backward")
+        return (None, None, None) + tuple(grads)
+
+
 class ClassAwareLoss(torch.autograd.Function):
     """class_aware_loss of trainer.py:298-311 on features (B, D) and int32 device labels (B,)."""
 

@@ -270,13 +270,24 @@ class condGANTrainer(object):
         if self.stack_d_passes and B % 8 == 0:
             x = torch.cat((self.real_imgs[idx], self.wrong_imgs[idx], self.fake_imgs[idx].detach()), 0)
             logits, _ = _unwrap(netD)(x, mu.repeat(3, 1), groups=3, need_features=False)
+            self._stacked_logits = logits
             return [[l[g * B:(g + 1) * B] for l in logits] for g in range(3)]
+        self._stacked_logits = None
         return [netD(self.real_imgs[idx], mu)[0], netD(self.wrong_imgs[idx], mu)[0],
                 netD(self.fake_imgs[idx].detach(), mu)[0]]
 
     def _d_loss(self, idx):
         u = cfg.TRAIN.COEFF.UNCOND_LOSS
         real_logits, wrong_logits, fake_logits = self._d_logits(idx)
+        if self._stacked_logits is not None and len(self._stacked_logits) == 2 and u > 0:
+            # the six BCE terms of trainer.py:394-409 on the stacked (real | wrong | fake) heads, one launch:
+            # cond targets 1/0/0, uncond targets 1/1/0 (wrong pairs count as real for the uncond head, :401)
+            dev = self._stacked_logits[0].device
+            key = (str(dev), float(u))
+            if getattr(self, '_bce_consts', (None,))[0] != key:
+                self._bce_consts = (key, torch.tensor([1., 1., 0., 1., 0., 0.], device=dev),
+                                    torch.tensor([1., u, 1., u, 1., u], device=dev))
+            return ops.BCEMulti.apply(self._bce_consts[1], self._bce_consts[2], 3, *self._stacked_logits)
         errD_real = ops.BCELoss.apply(real_logits[0], 1.0, 1.0)
         errD_wrong = ops.BCELoss.apply(wrong_logits[0], 0.0, 1.0)
         errD_fake = ops.BCELoss.apply(fake_logits[0], 0.0, 1.0)
