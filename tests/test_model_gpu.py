@@ -381,3 +381,44 @@ def test_full_size_config2_step_against_oracle(gpu):
                  atol=3e-4, what="D256 running_mean")
     k0 = 'ca_net.fc.weight'
     assert_close(tr.avg_param_G[0], ostate.avg_g[k0], rtol=1e-3, atol=1e-6, what="EMA")
+
+
+def test_training_loop_checkpoint_and_resume(gpu, tmp_path):
+    """condGANTrainer.train() over a tiny in-memory loader (the reference's tuple format, datasets.py:481):
+    runs epochs, writes Model/netG_<count>.pth + netD<i>.pth at the end, and a second trainer resumes from
+    them with the iteration count parsed from the file name (trainer.py:200-215, 527)."""
+    from speech_to_image_translation_without_text_amd import trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
+    case = dict(CASES['small3'], B=8)
+    from helpers import configure
+    configure(case)
+    cfg.TRAIN.MAX_EPOCH = 2
+    cfg.TRAIN.SNAPSHOT_INTERVAL = 1000
+    g = torch.Generator().manual_seed(2)
+
+    def sample():
+        imgs = [torch.rand(8, 3, 64 << i, 64 << i, generator=g) * 2 - 1 for i in range(3)]
+        wrong = [torch.rand(8, 3, 64 << i, 64 << i, generator=g) * 2 - 1 for i in range(3)]
+        return imgs, wrong, torch.randn(8, case['t'], generator=g), ['k'] * 8, torch.arange(8) % 3
+    loader = [sample(), sample()]
+    torch.manual_seed(0)
+    tr = T.condGANTrainer(str(tmp_path / "run"), loader, 256, False)
+    tr.train()
+    model_dir = tmp_path / "run" / "Model"
+    assert (model_dir / "netG_4.pth").exists() and all((model_dir / ("netD%d.pth" % i)).exists() for i in range(3))
+    sdG = torch.load(str(model_dir / "netG_4.pth"), weights_only=True, map_location="cpu")
+    assert all(k.startswith('module.') for k in sdG) and all(torch.isfinite(v.float()).all() for v in sdG.values())
+    assert int(sdG['module.h_net1.fc.1.num_batches_tracked']) == 4
+    # the saved generator is the EMA copy; the live weights kept training
+    live = tr.netG.state_dict()['module.ca_net.fc.weight'].cpu()
+    assert not torch.equal(live, sdG['module.ca_net.fc.weight'])
+    # resume
+    cfg.TRAIN.NET_G = str(model_dir / "netG_4.pth")
+    cfg.TRAIN.NET_D = str(model_dir / "netD")
+    cfg.TRAIN.MAX_EPOCH = 3
+    tr2 = T.condGANTrainer(str(tmp_path / "run2"), loader, 256, False)
+    start = tr2.build()
+    assert start == 5
+    assert torch.equal(tr2.netG.state_dict()['module.ca_net.fc.weight'].cpu(), sdG['module.ca_net.fc.weight'])
+    cfg.TRAIN.NET_G = cfg.TRAIN.NET_D = ''
+    cfg.TRAIN.MAX_EPOCH = 600
