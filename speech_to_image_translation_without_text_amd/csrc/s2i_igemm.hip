@@ -36,6 +36,7 @@ struct IgemmP {
   int kind, flip, act, stats, splitk, cps, nchunks;
   int ldw, wR, ldy, nparts;
   int g_kw, g_s, g_pad;  // geometry of S2I_CONV_1D (1 x kw taps along W, stride, padding)
+  int wt;                // weights read transposed per tap (small_n_conv_kernel; the igemm takes it as a template flag)
   unsigned x_bytes, c_bytes, w_bytes;
   long long Mrows;
 };
@@ -387,6 +388,78 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
         p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
         p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
       }
+    }
+  }
+}
+
+// Convolutions with at most 4 output channels (GET_IMAGE_G's conv3x3 -> RGB, model.py:287-298, and the input
+// gradient of the discriminators' first conv): HBM-bound, so no matrix cores.  LPP = Ca/4 lanes share one output
+// pixel, each multiplying its 4 input channels into the 4 outputs (weights [t][c][4] in LDS), then a shuffle
+// reduction; a wave reads PPW = 64/LPP whole pixels per tap, i.e. contiguous NHWC bytes.
+template <int LPP>
+__global__ __launch_bounds__(256) void small_n_conv_kernel(IgemmP p) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [T][Ca][4]
+  constexpr int PPW = 64 / LPP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int phase = blockIdx.z;
+  const int py = phase >> 1, px = phase & 1;
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+  // stage the 4 output columns of every (tap, channel) row
+  for (int e = tid; e < p.T * p.Ca; e += 256) {
+    const int t = e / p.Ca, c = e - t * p.Ca;
+    const int tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (p.wt) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (n < p.N) v[n] = p.w[((size_t)tw * p.wR + n) * p.ldw + c];
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (n < p.N && n < p.ldw) v[n] = p.w[((size_t)tw * p.wR + c) * p.ldw + n];
+    }
+    *reinterpret_cast<f32x4*>(wl + e * 4) = v;
+  }
+  __syncthreads();
+  const int q = lane % LPP, pl = lane / LPP;
+  const int m = (blockIdx.x * 4 + wave) * PPW + pl;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int b = 0, oy = 0, ox = 0;
+  if (m < p.M) {
+    b = m >> p.lgHoWo;
+    const int r = m & ((1 << p.lgHoWo) - 1);
+    oy = r >> p.lgWo;
+    ox = r & (p.Wo - 1);
+    const int by = oy * s - pad, bx = ox * s - pad;
+    const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
+    const float* xb = p.x + (((long long)b * p.H + by) * p.W + bx) * p.Cx + q * 4;
+    for (int t = 0; t < p.T; ++t) {
+      if (!((mask >> t) & 1u)) continue;
+      int dy, dx;
+      tap_delta(p.kind, kw, t, py, px, dy, dx);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((long long)dy * p.W + dx) * p.Cx);
+      const float* wp = wl + ((size_t)t * p.Ca + q * 4) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc += xv[j] * *reinterpret_cast<const f32x4*>(wp + j * 4);
+    }
+  }
+#pragma unroll
+  for (int sft = 1; sft < LPP; sft <<= 1)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], sft);
+  if (q == 0 && m < p.M) {
+    long long row = m;
+    if (p.kind == S2I_TCONV_K4S2) row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      if (n >= p.N) break;
+      float v = acc[n];
+      if (p.bias) v += p.bias[n];
+      if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+      else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+      else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+      p.y[row * p.ldy + n] = v;
     }
   }
 }
@@ -840,8 +913,21 @@ extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, cons
   p.kind = d->kind; p.flip = d->flip; p.act = d->act; p.stats = d->stats;
   p.splitk = pl.splitk; p.cps = pl.cps; p.nchunks = pl.nchunks;
   p.ldw = d->ldw; p.wR = d->wR; p.ldy = d->ldy; p.nparts = pl.gridM * pl.nphases;
-  p.g_kw = d->kw; p.g_s = d->stride; p.g_pad = d->pad;
+  p.g_kw = d->kw; p.g_s = d->stride; p.g_pad = d->pad; p.wt = d->wmode != 0;
   p.Mrows = pl.Mrows;
+  if (d->N <= 4 && d->Cc == 0 && !d->stats && !cls_bias && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
+      (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) && pl.M >= 4096) {
+    // HBM-bound RGB-sized layers: VALU kernel instead of a 32-wide MFMA tile that is 7/8 padding
+    p.wt = d->wmode != 0;
+    const int lpp = pl.Ca / 4, ppw = 64 / lpp;
+    dim3 sgrid(s2i_cdiv(pl.M, 4 * ppw), 1, pl.nphases);
+    const size_t shb = (size_t)pl.T * pl.Ca * 4 * sizeof(float);
+    if (lpp == 4) hipLaunchKernelGGL((small_n_conv_kernel<4>), sgrid, dim3(256), shb, st, p);
+    else if (lpp == 8) hipLaunchKernelGGL((small_n_conv_kernel<8>), sgrid, dim3(256), shb, st, p);
+    else hipLaunchKernelGGL((small_n_conv_kernel<16>), sgrid, dim3(256), shb, st, p);
+    S2I_LAUNCH_CHECK("small_n_conv");
+    return 0;
+  }
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   const bool wt = d->wmode != 0;
   const int wtaps = d->kind == S2I_TCONV_K4S2 ? 16 : pl.T;

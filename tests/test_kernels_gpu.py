@@ -149,6 +149,9 @@ CONVACT = [
     ("k4s2", 2, 16, 3, 4, 16, 16, "lrelu", False),   # first D conv on an NHWC4 image
     ("k3s1", 2, 16, 16, 16, 3, 4, "tanh", False),    # GET_IMAGE_G -> NHWC4 image
     ("k1", 4, 1, 64, 64, 32, 32, "none", True),      # CA_NET.fc
+    ("k3s1", 2, 64, 16, 16, 3, 4, "tanh", False),    # GET_IMAGE_G at scale: VALU small-N kernel (4 lanes / pixel)
+    ("k3s1", 2, 64, 64, 64, 3, 4, "tanh", False),    # ... 16 lanes / pixel
+    ("k4s2", 2, 128, 3, 4, 64, 64, "lrelu", False),  # first D conv at scale: its input gradient is the small-N tconv
 ]
 
 
