@@ -20,7 +20,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import (ACT_GLU, ACT_LRELU, ACT_NONE, ACT_TANH, CONV_K1, CONV_K3S1, CONV_K4S2,
+from ._lib import (ACT_GLU, ACT_NONE, CONV_K1, CONV_K3S1, CONV_K4S2,
                    PACK_PLAIN, PACK_UPFOLD, TCONV_K4S2, ConvDesc, WgradDesc, check, ptr, stream)
 
 BN_EPS = 1e-5
@@ -97,10 +97,6 @@ def refresh_packed(params):
                     packs[mode] = (pack_weight(p, mode, out=ent[0]), p._version, p.data_ptr())
                 else:
                     del packs[mode]
-
-
-def clear_caches():
-    pass
 
 
 def pack_weight(w, mode, out=None):
@@ -687,9 +683,6 @@ def increment(counter):
     check(lib.s2i_increment(ptr(counter), stream()), "s2i_increment")
 
 
-def scale_(t, a):
-    lib = _lib_ready()
-    check(lib.s2i_axpby(ptr(t), ptr(t), t.numel(), a, 0.0, stream()), "s2i_axpby")
 
 
 # ---- evaluation output ---------------------------------------------------------------------------------------------

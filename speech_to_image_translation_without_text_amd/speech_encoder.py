@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from ._lib import ACT_NONE, ACT_RELU, CONV_1D, CONV_K1, PACK_PLAIN, check, ptr, stream
+from ._lib import ACT_RELU, CONV_1D, CONV_K1, PACK_PLAIN, check, ptr, stream
 
 
 def conv_layer_2d(in_channel, out_channel, kernel_size, stride, padding):

@@ -4,7 +4,6 @@ Records the (descriptor, count) of every s2i_conv_forward / s2i_conv_wgrad call 
 cfg/birds_3stages.yml step, then times each unique descriptor in isolation with HIP events.
 """
 import collections
-import ctypes
 import os
 import sys
 
@@ -12,7 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from speech_to_image_translation_without_text_amd import _lib, model, ops, trainer as T  # noqa: E402
+from speech_to_image_translation_without_text_amd import model, ops, trainer as T  # noqa: E402
 from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file  # noqa: E402
 
 KIND = {0: "k1", 1: "k3s1", 2: "k4s2", 3: "tconv"}
