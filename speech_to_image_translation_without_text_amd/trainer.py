@@ -31,6 +31,17 @@ from .model import D_NET64, D_NET128, D_NET256, D_NET512, D_NET1024, G_NET, INCE
 
 
 # ---- shared functions --------------------------------------------------------------------------------
+def compute_mean_covariance(img):
+    """Per-image channel mean (B,C,1,1) and C x C covariance over pixels (trainer.py:34-51).  Dormant in every
+    BASELINE config (COLOR_LOSS = 0): plain torch ops on 3-channel images, no kernel of its own."""
+    batch_size, channel_num, height, width = img.shape
+    num_pixels = height * width
+    mu = img.mean(2, keepdim=True).mean(3, keepdim=True)
+    img_hat = (img - mu.expand_as(img)).view(batch_size, channel_num, num_pixels)
+    covariance = torch.bmm(img_hat, img_hat.transpose(1, 2)) / num_pixels
+    return mu, covariance
+
+
 def KL_loss(mu, logvar):
     return ops.KLLoss.apply(mu, logvar)
 
@@ -340,8 +351,14 @@ class condGANTrainer(object):
                     errG_cal_total = errG_cal_total + ops.ClassAwareLoss.apply(x_active, labels_dev)
                 errG_total = errG_total + errG
             if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
-                raise NotImplementedError("colour-consistency loss (trainer.py:455-478) is dormant in every "
-                                          "BASELINE config and not built on this path")
+                # colour-consistency between neighbouring scales (trainer.py:455-478); dormant by default
+                coef = cfg.TRAIN.COEFF.COLOR_LOSS
+                for hi, lo in ((-1, -2), (-2, -3)):
+                    if self.num_Ds >= -lo:
+                        mu1, cov1 = compute_mean_covariance(self.fake_imgs[hi])
+                        mu2, cov2 = compute_mean_covariance(self.fake_imgs[lo].detach())
+                        errG_total = errG_total + coef * nn.functional.mse_loss(mu1, mu2) \
+                            + coef * 5 * nn.functional.mse_loss(cov1, cov2)
             kl_loss = KL_loss(self.mu, self.logvar) * cfg.TRAIN.COEFF.KL
             errG_total = errG_total + kl_loss + errG_cal_total
             errG_total.backward()
