@@ -96,23 +96,49 @@ __device__ __forceinline__ int tap_weight(int kind, int flip, int T, int t, int 
   return flip ? (T - 1 - t) : t;
 }
 
+// One 32-deep K chunk: 16 k-pairs, each TM x TN v_mfma_f32_32x32x2_f32.  The fragments of pair kk+1 are read
+// from LDS BEFORE the MFMAs of pair kk are issued (two register sets), so the LDS latency sits behind 4+ MFMAs
+// of this wave instead of relying on the other waves of the SIMD to cover it.
 template <int TM, int TN, int LDA, int LDB, int KK0 = 0, int KK1 = 16>
 __device__ __forceinline__ void mma_chunk(const float* As, const float* Bs, int arow0, int bcol0,
                                           int lane, f32x16 (&acc)[TM][TN]) {
+  static_assert((KK1 - KK0) % 2 == 0, "k-pairs are processed two at a time");
   const int l31 = lane & 31, lh = lane >> 5;
+  const float* ap = As + lh * LDA + arow0 + l31;
+  const float* bp = Bs + lh * LDB + bcol0 + l31;
+  float a0[TM], b0[TN], a1[TM], b1[TN];  // two named fragment sets (a runtime-indexed pair would go to scratch)
 #pragma unroll
-  for (int kk = KK0; kk < KK1; ++kk) {
-    const int k = 2 * kk + lh;
-    float a[TM], b[TN];
+  for (int i = 0; i < TM; ++i) a0[i] = ap[(2 * KK0) * LDA + i * 32];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) a[i] = As[k * LDA + arow0 + i * 32 + l31];
+  for (int j = 0; j < TN; ++j) b0[j] = bp[(2 * KK0) * LDB + j * 32];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b[j] = Bs[k * LDB + bcol0 + j * 32 + l31];
+  for (int kk = KK0; kk < KK1; kk += 2) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a1[i] = ap[(2 * (kk + 1)) * LDA + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b1[j] = bp[(2 * (kk + 1)) * LDB + j * 32];
+    // pin the order (hipcc otherwise sinks the reads next to their use): next pair's LDS reads, THEN this pair's
+    // MFMAs.  Only for the 2x2 wave tile: with fewer MFMAs per pair the pinned schedule makes hipcc spill.
+    if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+    if (kk + 2 < KK1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a0[i] = ap[(2 * (kk + 2)) * LDA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b0[j] = bp[(2 * (kk + 2)) * LDB + j * 32];
+    }
+    if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+    if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
   }
 }
 
