@@ -44,19 +44,21 @@ def _lib_ready():
 
 # ---- scratch ------------------------------------------------------------------------------------
 class _Workspace:
-    """One growable scratch buffer per device; kernels on a stream use it one after another."""
+    """One growable scratch buffer per (device, stream): kernels on a stream use it one after another, and two
+    streams never share one."""
 
     def __init__(self):
         self.buf = {}
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 16)
-        cur = self.buf.get(device)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        cur = self.buf.get(key)
         if cur is None or cur.numel() * 4 < nbytes:
             if torch.cuda.is_current_stream_capturing():
                 raise _lib.S2IError("workspace would grow during hipGraph capture; run a warm-up step first")
             cur = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
-            self.buf[device] = cur
+            self.buf[key] = cur
         return cur
 
 

@@ -17,6 +17,7 @@ What is built differently (MI355X-first):
 The Inception-v3 forwards, IS/FID and image dumps of the reference loop are evaluation-side and out
 of scope; the loop here runs the update and the checkpoint layout only.
 """
+import contextlib
 import os
 import time
 from copy import deepcopy
@@ -233,6 +234,10 @@ class condGANTrainer(object):
         self.world = torch.distributed.get_world_size() if distributed else 1
         self._pending = []
         self.stack_d_passes = True
+        # independent discriminator passes on separate HIP streams (S2I_D_STREAMS=0 turns it off)
+        self.d_streams = os.environ.get("S2I_D_STREAMS", "1") == "1" and torch.cuda.is_available()
+        self._side_streams = None
+        self._g_streams = None
 
     # -- set-up -------------------------------------------------------------------------------------------
     def build(self, netG=None, netsD=None, start_count=0):
@@ -337,19 +342,35 @@ class condGANTrainer(object):
         errG_total = 0
         errG_cal_total = 0
         labels_dev = None
+        per_d = []
         for f in self.flatsD:
             f.set_requires_grad(False)  # their weight gradients would be discarded (trainer.py:385)
         try:
+            # the per-scale discriminator passes are independent until their losses are summed: with d_streams each
+            # runs on its own HIP stream (autograd replays every backward on its forward stream)
+            main = torch.cuda.current_stream() if self.d_streams else None
+            if self.d_streams and self._g_streams is None:
+                self._g_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
             for i in range(self.num_Ds):
-                outputs, x_active = self.netsD[i](self.fake_imgs[i], self.mu)
-                errG = ops.BCELoss.apply(outputs[0], 1.0, 1.0)
-                if len(outputs) > 1 and u > 0:
-                    errG = errG + ops.BCELoss.apply(outputs[1], 1.0, u)
-                if cfg.TRAIN.COEFF.CAL_LOSS > 0:
-                    if labels_dev is None:
-                        labels_dev = class_labels_to_device(self.class_labels, x_active.device)
-                    errG_cal_total = errG_cal_total + ops.ClassAwareLoss.apply(x_active, labels_dev)
-                errG_total = errG_total + errG
+                if self.d_streams:
+                    self._g_streams[i].wait_stream(main)
+                    ctx = torch.cuda.stream(self._g_streams[i])
+                else:
+                    ctx = contextlib.nullcontext()
+                with ctx:
+                    outputs, x_active = self.netsD[i](self.fake_imgs[i], self.mu)
+                    errG = ops.BCELoss.apply(outputs[0], 1.0, 1.0)
+                    if len(outputs) > 1 and u > 0:
+                        errG = errG + ops.BCELoss.apply(outputs[1], 1.0, u)
+                    if cfg.TRAIN.COEFF.CAL_LOSS > 0:
+                        if labels_dev is None:
+                            labels_dev = class_labels_to_device(self.class_labels, x_active.device)
+                        errG = errG + ops.ClassAwareLoss.apply(x_active, labels_dev).reshape(())
+                per_d.append(errG)
+            for i in range(self.num_Ds):
+                if self.d_streams:
+                    main.wait_stream(self._g_streams[i])
+                errG_total = errG_total + per_d[i]
             if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
                 # colour-consistency between neighbouring scales (trainer.py:455-478); dormant by default
                 coef = cfg.TRAIN.COEFF.COLOR_LOSS
@@ -378,10 +399,27 @@ class condGANTrainer(object):
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
         errD_total = 0
-        # the D updates are independent of each other: largest first, so that its gradient all-reduce
-        # (285 MB for D_NET256) hides behind the smaller discriminators' forward/backward
-        for i in reversed(range(self.num_Ds)):
-            errD_total = errD_total + self.train_Dnet(i, 0, defer_step=True)
+        if self.d_streams and self.num_Ds >= 2:
+            # the D updates are independent: each runs on its own HIP stream, so the many short kernels of one fill
+            # the idle CUs of the others; the Adam steps wait for all of them
+            main = torch.cuda.current_stream()
+            if self._side_streams is None:
+                self._side_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
+            errs = []
+            for i in reversed(range(self.num_Ds)):  # largest first: its all-reduce has the most to hide behind
+                st = self._side_streams[i]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    errs.append(self.train_Dnet(i, 0, defer_step=True))
+            for st in self._side_streams:
+                main.wait_stream(st)
+            for e in errs:
+                errD_total = errD_total + e
+        else:
+            # largest first, so that its gradient all-reduce (285 MB for D_NET256) hides behind the smaller
+            # discriminators' forward/backward
+            for i in reversed(range(self.num_Ds)):
+                errD_total = errD_total + self.train_Dnet(i, 0, defer_step=True)
         self._flush_d_steps()
         kl_loss, errG_total = self.train_Gnet(0)
         self.flatG.ema(0.999)
