@@ -36,6 +36,32 @@ def _direct(p):
     return DIRECT_PARAM_GRAD and p is not None and p.grad is not None and p.grad.is_contiguous()
 
 
+# In direct mode the weight-gradient GEMMs are off the backward critical path (nothing downstream reads them
+# until the optimiser): when WGRAD_SIDE_STREAM is on they are launched on a companion HIP stream of the stream
+# the backward runs on, so they fill the CUs left idle by the short BatchNorm / reduction kernels of the
+# input-gradient chain.  `join_wgrad_streams()` must run before the gradients are consumed.
+WGRAD_SIDE_STREAM = False
+_wgrad_streams = {}
+
+
+def _wgrad_stream():
+    cur = torch.cuda.current_stream()
+    side = _wgrad_streams.get(cur.cuda_stream)
+    if side is None:
+        side = torch.cuda.Stream()
+        _wgrad_streams[cur.cuda_stream] = side
+    return cur, side
+
+
+def join_wgrad_streams():
+    """Make the current stream wait for every companion weight-gradient stream."""
+    if not _wgrad_streams:
+        return
+    cur = torch.cuda.current_stream()
+    for side in _wgrad_streams.values():
+        cur.wait_stream(side)
+
+
 def _lib_ready():
     lib = _lib.load()
     _lib.require_device()
@@ -227,10 +253,22 @@ def _dgrad(kind_name, dy, w, packed, n_in):
 def _wgrad(kind_name, x, cvec, dy, weight):
     """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode."""
     out, acc = (weight.grad, True) if _direct(weight) else (None, False)
-    if kind_name == "up":
-        dw = wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
-    else:
-        dw = wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
+
+    def run():
+        if kind_name == "up":
+            return wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
+        return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
+
+    if acc and WGRAD_SIDE_STREAM:
+        cur, side = _wgrad_stream()
+        side.wait_stream(cur)                 # dy (and x) are complete on the backward's stream
+        for t in (x, cvec, dy):
+            if t is not None:
+                t.record_stream(side)         # the allocator must not recycle them under the side stream
+        with torch.cuda.stream(side):
+            run()
+        return None
+    dw = run()
     return None if acc else dw
 
 

@@ -167,6 +167,7 @@ class FlatNet:
             p.requires_grad_(flag)
 
     def adam(self, gscale=1.0):
+        ops.join_wgrad_streams()  # weight gradients may still be in flight on their companion streams
         ops.increment(self.step_dev)
         self.step_count += 1
         ops.adam_step(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
@@ -273,6 +274,7 @@ class condGANTrainer(object):
     def _reduce_async(self, flat):
         if not self.distributed:
             return None
+        ops.join_wgrad_streams()  # the flat gradient buffer must be complete before it is reduced
         return torch.distributed.all_reduce(flat.g, op=torch.distributed.ReduceOp.SUM, async_op=True)
 
     # -- D update (trainer.py:375-427) ----------------------------------------------------------------------------
@@ -395,6 +397,9 @@ class condGANTrainer(object):
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
         ops.DIRECT_PARAM_GRAD = True  # kernels accumulate into the flat gradient buffers (zeroed per update)
+        # opt-in (S2I_WGRAD_STREAM=1): -0.5 ms/step on one GPU, but the record_stream bookkeeping it needs made a
+        # two-process rehearsal on one shared GPU 6x slower, and it cannot be validated on a multi-GPU node here
+        ops.WGRAD_SIDE_STREAM = self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"
         self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
