@@ -238,7 +238,6 @@ class condGANTrainer(object):
         # independent discriminator passes on separate HIP streams (S2I_D_STREAMS=0 turns it off)
         self.d_streams = os.environ.get("S2I_D_STREAMS", "1") == "1" and torch.cuda.is_available()
         self._side_streams = None
-        self._g_streams = None
 
     # -- set-up -------------------------------------------------------------------------------------------
     def build(self, netG=None, netsD=None, start_count=0):
@@ -351,12 +350,12 @@ class condGANTrainer(object):
             # the per-scale discriminator passes are independent until their losses are summed: with d_streams each
             # runs on its own HIP stream (autograd replays every backward on its forward stream)
             main = torch.cuda.current_stream() if self.d_streams else None
-            if self.d_streams and self._g_streams is None:
-                self._g_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
+            if self.d_streams and self._side_streams is None:
+                self._side_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
             for i in range(self.num_Ds):
                 if self.d_streams:
-                    self._g_streams[i].wait_stream(main)
-                    ctx = torch.cuda.stream(self._g_streams[i])
+                    self._side_streams[i].wait_stream(main)  # fake images / mu; D_i's own update is already in order
+                    ctx = torch.cuda.stream(self._side_streams[i])
                 else:
                     ctx = contextlib.nullcontext()
                 with ctx:
@@ -371,7 +370,7 @@ class condGANTrainer(object):
                 per_d.append(errG)
             for i in range(self.num_Ds):
                 if self.d_streams:
-                    main.wait_stream(self._g_streams[i])
+                    main.wait_stream(self._side_streams[i])
                 errG_total = errG_total + per_d[i]
             if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
                 # colour-consistency between neighbouring scales (trainer.py:455-478); dormant by default
@@ -405,29 +404,28 @@ class condGANTrainer(object):
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
         errD_total = 0
         if self.d_streams and self.num_Ds >= 2:
-            # the D updates are independent: each runs on its own HIP stream, so the many short kernels of one fill
-            # the idle CUs of the others; the Adam steps wait for all of them
+            # the D updates are independent: each runs on its own HIP stream (zero, stacked forward, backward,
+            # all-reduce, Adam, re-pack), so the many short kernels of one fill the idle CUs of the others.  The
+            # same stream later carries that discriminator's pass of the G update, so D_i's part of the G update
+            # can start as soon as D_i is updated, while a larger discriminator is still in its own update.
             main = torch.cuda.current_stream()
             if self._side_streams is None:
                 self._side_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
             errs = []
-            for i in reversed(range(self.num_Ds)):  # largest first: its all-reduce has the most to hide behind
+            for i in reversed(range(self.num_Ds)):  # largest first: it is the critical path
                 st = self._side_streams[i]
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
-                    errs.append(self.train_Dnet(i, 0, defer_step=True))
-            for st in self._side_streams:
-                main.wait_stream(st)
-            for e in errs:
-                errD_total = errD_total + e
+                    errs.append(self.train_Dnet(i, 0))
         else:
             # largest first, so that its gradient all-reduce (285 MB for D_NET256) hides behind the smaller
             # discriminators' forward/backward
-            for i in reversed(range(self.num_Ds)):
-                errD_total = errD_total + self.train_Dnet(i, 0, defer_step=True)
-        self._flush_d_steps()
-        kl_loss, errG_total = self.train_Gnet(0)
+            errs = [self.train_Dnet(i, 0, defer_step=True) for i in reversed(range(self.num_Ds))]
+            self._flush_d_steps()
+        kl_loss, errG_total = self.train_Gnet(0)  # joins the discriminator streams before its backward
         self.flatG.ema(0.999)
+        for e in errs:
+            errD_total = errD_total + e
         return errD_total, errG_total, kl_loss
 
     def train(self):
