@@ -661,6 +661,81 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
     }
 }
 
+// Weight gradient of a 3x3 convolution with at most 4 output channels (GET_IMAGE_G's conv3x3 -> RGB, model.py:287-298):
+// K x N = (9 * Ca) x 4 is far too small for matrix cores and the operands are read exactly once, so this is an
+// HBM stream.  LPP = Ca/4 lanes share one INPUT pixel (a wave reads 64 consecutive float4 = 1 KB of NHWC), each lane
+// multiplies its 4 channels with the float4 output gradient of the 9 output pixels that see this input pixel and
+// keeps all 9 x 4 x 4 products in registers across its pixel loop.  One slab [9*Ca][4] per block.
+template <int LPP>
+__global__ __launch_bounds__(256) void small_n_wgrad_kernel(WgradP p) {
+  constexpr int PPW = 64 / LPP;
+  __shared__ f32x4 red[4][9 * LPP * 4];  // [wave][tap][q][j]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane % LPP, pl = lane / LPP;
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ngroups = p.M / PPW;  // W is a power of two >= PPW, so a group never straddles an image row
+  const int wmask = p.W - 1;
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int m = grp * PPW + pl;
+    const int ix = m & wmask;
+    const int iy = (m >> p.lgWo) & (p.H - 1);
+    const f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)m * p.Ca + q * 4);
+    const float* gp = p.g + (size_t)m * 4;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int oy = iy + 1 - dy;
+      if (oy < 0 || oy >= p.H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ox = ix + 1 - dx;
+        if (ox < 0 || ox >= p.W) continue;
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + ((1 - dy) * p.W + (1 - dx)) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[dy * 3 + dx][j] += av[j] * gv;
+      }
+    }
+  }
+  // lanes with equal q (different pixels) -> lane q
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[t][j];
+#pragma unroll
+      for (int sft = LPP; sft < 64; sft <<= 1)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) v[n] += __shfl_xor(v[n], sft);
+      if (pl == 0) red[wave][(t * LPP + q) * 4 + j] = v;
+    }
+  __syncthreads();
+  float* outp = p.slab + (size_t)blockIdx.x * p.K * 4;
+  for (int e = tid; e < 9 * LPP * 4; e += 256) {
+    const f32x4 v = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    *reinterpret_cast<f32x4*>(outp + (size_t)e * 4) = v;  // e = tap * Ca + channel: the slab's K row
+  }
+}
+
+// slab[0] = sum_s slab[s] for a SMALL K x N (n4 float4) and many slabs: one block per 4 float4, 64 slab lanes each
+__global__ __launch_bounds__(256) void slab_sum_tree_kernel(float* __restrict__ slab, int S, int n4) {
+  __shared__ f32x4 sh[256];
+  const int tid = threadIdx.x;
+  const int e = blockIdx.x * 4 + (tid & 3), sl = tid >> 2;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (e < n4)
+    for (int s = sl; s < S; s += 64) v += *reinterpret_cast<const f32x4*>(slab + ((size_t)s * n4 + e) * 4);
+  sh[tid] = v;
+  __syncthreads();
+  for (int h = 32; h >= 1; h >>= 1) {
+    if (sl < h) sh[tid] += sh[tid + h * 4];
+    __syncthreads();
+  }
+  if (sl == 0 && e < n4) *reinterpret_cast<f32x4*>(slab + (size_t)e * 4) = sh[tid];
+}
+
 // slab[0] += slab[1..S-1]: a pure float4 stream over the split slabs (full-chip parallel, HBM-bound)
 __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ slab, int S, long long n4) {
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4;
@@ -834,7 +909,7 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
 }
 
 struct WgPlan {
-  int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps;
+  int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps, small_n;
 };
 
 int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
@@ -861,17 +936,24 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   if (d->swap) S2I_REQUIRE(pl->Cin >= d->O && d->N == d->I, "wgrad(swap): shape mismatch");
   else S2I_REQUIRE(pl->Cin >= d->I && d->N >= d->O, "wgrad: shape mismatch");
   pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
-  const int BN = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
-  pl->gridK = s2i_cdiv(pl->K, 128);
+  if (pl->K <= 64 && d->N > 32 && d->N <= 64) pl->tile = 3;  // first discriminator conv: 16 taps x (3+1) channels
+  const int BN = pl->tile == 0 ? 128 : (pl->tile == 2 ? 32 : 64);
+  const int BM = pl->tile == 3 ? 64 : 128;
+  pl->gridK = s2i_cdiv(pl->K, BM);
   pl->gridN = s2i_cdiv(d->N, BN);
   pl->nchunks = s2i_cdiv(M, 32);
   const long long tiles = (long long)pl->gridK * pl->gridN;
-  int splitk = (int)((512 + tiles - 1) / tiles);
+  // three resident blocks per CU hide each other's load latency: aim at one full wave of 3 x 256 blocks
+  int splitk = (int)(768 / tiles);
   if (splitk > pl->nchunks / 4) splitk = pl->nchunks / 4;
   if (splitk > 256) splitk = 256;
   if (splitk < 1) splitk = 1;
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  // <= 4 output channels of a 3x3 conv: streamed on the vector units, one slab per block
+  pl->small_n = d->kind == S2I_CONV_K3S1 && d->Cc == 0 && d->N == 4 && d->ldg == 4 &&
+                (d->Ca == 16 || d->Ca == 32 || d->Ca == 64) && d->W >= 16 && M >= (1 << 15);
+  if (pl->small_n) pl->splitk = 512;
   return 0;
 }
 
@@ -1021,9 +1103,14 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
-  if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+  if (pl.small_n) {
+    if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
+    else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(small_n_wgrad_kernel<16>, dim3(pl.splitk), dim3(256), 0, st, p);
+  } else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
+  else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
   S2I_LAUNCH_CHECK("igemm_wgrad");
   {
     const int ncols = d->swap ? d->I : d->O, nrows = d->swap ? d->O : d->I;
@@ -1035,7 +1122,11 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     // float4 stream folds the split slabs into slab 0, then the tile kernel transposes slab 0 into OIHW
     int S = pl.splitk;
     const long long kn = (long long)pl.K * d->N;
-    if (S > 2 && (kn % 4) == 0) {
+    if (pl.small_n) {
+      hipLaunchKernelGGL(slab_sum_tree_kernel, dim3(s2i_cdiv(kn / 4, 4)), dim3(256), 0, st, (float*)ws, S, (int)(kn / 4));
+      S2I_LAUNCH_CHECK("slab_sum_tree");
+      S = 1;
+    } else if (S > 2 && (kn % 4) == 0) {
       int sb = s2i_cdiv(kn / 4, 256);
       if (sb > 4096) sb = 4096;
       hipLaunchKernelGGL(slab_sum_kernel, dim3(sb), dim3(256), 0, st, (float*)ws, S, kn / 4);

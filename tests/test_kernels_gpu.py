@@ -152,6 +152,9 @@ CONVACT = [
     ("k3s1", 2, 64, 16, 16, 3, 4, "tanh", False),    # GET_IMAGE_G at scale: VALU small-N kernel (4 lanes / pixel)
     ("k3s1", 2, 64, 64, 64, 3, 4, "tanh", False),    # ... 16 lanes / pixel
     ("k4s2", 2, 128, 3, 4, 64, 64, "lrelu", False),  # first D conv at scale: its input gradient is the small-N tconv
+    ("k3s1", 2, 128, 16, 16, 3, 4, "tanh", False),   # weight gradient streamed by small_n_wgrad_kernel<4>
+    ("k3s1", 2, 128, 32, 32, 3, 4, "tanh", False),   # ... <8>
+    ("k3s1", 2, 128, 64, 64, 3, 4, "tanh", False),   # ... <16>
 ]
 
 
