@@ -199,6 +199,10 @@ int s2i_nhwc_to_nchw(const float* src, int lds, float* dst, int B, int C, int H,
 /* [-1,1] float image (NHWC, row stride lds, first 3 channels) -> HWC uint8 RGB, the reference's
    `img.add(1).div(2).mul(255).clamp(0, 255).byte()` (trainer.py:676) fused with its permute(1,2,0) */
 int s2i_image_to_u8(const float* src, int lds, unsigned char* dst, long long npix, void* stream);
+/* HWC uint8 RGB [B][H][W][3] -> normalised NCHW float [B][3][H][W]: the reference's per-sample
+   `ToTensor()` (x / 255) followed by `Normalize((.5,.5,.5), (.5,.5,.5))` ((t - 0.5) / 0.5), datasets.py:440-442,
+   applied on the device to the collated uint8 batch (same fp32 operations in the same order: bit-identical) */
+int s2i_u8_to_image(const unsigned char* src, float* dst, int B, int H, int W, void* stream);
 /* sum over the H*W rows of each image of the first C columns of a [B*HW][ld] tensor -> [B][C] */
 int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, float* dst, void* ws,
                     size_t ws_bytes, void* stream);

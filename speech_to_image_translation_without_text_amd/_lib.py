@@ -60,6 +60,7 @@ _SIGNATURES = {
     "s2i_nchw_to_nhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "s2i_nhwc_to_nchw": (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, P]),
     "s2i_image_to_u8": (c_int, [P, c_int, P, c_ll, P]),
+    "s2i_u8_to_image": (c_int, [P, P, c_int, c_int, c_int, P]),
     "s2i_spatial_sum": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "s2i_spatial_sum_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "s2i_reparam_forward": (c_int, [P, P, c_int, c_int, P, P]),

@@ -435,6 +435,22 @@ __global__ void image_to_u8_kernel(const float* __restrict__ src, int lds, unsig
   }
 }
 
+// HWC uint8 -> normalised NCHW float: consecutive threads take consecutive pixels, so the 3-byte reads and the three
+// plane writes are all coalesced
+__global__ void u8_to_image_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int HW,
+                                   long long npix) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < npix;
+       e += (long long)gridDim.x * blockDim.x) {
+    const long long b = e / HW;
+    const long long r = e - b * HW;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float t = (float)src[e * 3 + c] / 255.f;          // ToTensor
+      dst[(b * 3 + c) * HW + r] = (t - 0.5f) / 0.5f;          // Normalize
+    }
+  }
+}
+
 // per-image column sums, two stages: [B][S][C] partials then the S-sum
 __global__ __launch_bounds__(256) void spatial_sum_stage1(const float* __restrict__ src, int ld, int HW, int C,
                                                           int S, float* __restrict__ tmp, int cpb) {
@@ -1074,6 +1090,14 @@ extern "C" int s2i_image_to_u8(const float* src, int lds, unsigned char* dst, lo
   S2I_REQUIRE(src && dst && lds >= 3 && npix > 0, "image_to_u8: bad args");
   hipLaunchKernelGGL(image_to_u8_kernel, dim3(grid_for(npix)), dim3(256), 0, ST, src, lds, dst, npix);
   S2I_LAUNCH_CHECK("image_to_u8");
+  return 0;
+}
+
+extern "C" int s2i_u8_to_image(const unsigned char* src, float* dst, int B, int H, int W, void* stream) {
+  S2I_REQUIRE(src && dst && B > 0 && H > 0 && W > 0, "u8_to_image: bad args");
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(u8_to_image_kernel, dim3(grid_for(npix)), dim3(256), 0, ST, src, dst, H * W, npix);
+  S2I_LAUNCH_CHECK("u8_to_image");
   return 0;
 }
 

@@ -735,3 +735,16 @@ def images_to_uint8_hwc(img_nhwc):
     out = torch.empty((B, H, W, 3), dtype=torch.uint8, device=img_nhwc.device)
     check(lib.s2i_image_to_u8(ptr(t), ld, ptr(out), B * H * W, stream()), "s2i_image_to_u8")
     return out
+
+
+# ---- data edge -----------------------------------------------------------------------------------------------------
+def images_from_uint8_hwc(u8):
+    """(B,H,W,3) uint8 RGB on the device -> (B,3,H,W) float in [-1,1]: the reference's per-sample
+    ToTensor + Normalize(0.5, 0.5) (datasets.py:440-442) applied to the collated batch on the GPU, so the
+    host->device copy carries 1 byte per sample instead of 4."""
+    lib = _lib_ready()
+    assert u8.dtype == torch.uint8 and u8.dim() == 4 and u8.shape[-1] == 3 and u8.is_contiguous()
+    B, H, W, _ = u8.shape
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=u8.device)
+    check(lib.s2i_u8_to_image(ptr(u8), ptr(out), B, H, W, stream()), "s2i_u8_to_image")
+    return out

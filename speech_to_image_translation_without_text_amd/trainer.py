@@ -265,8 +265,12 @@ class condGANTrainer(object):
             imgs, w_imgs, t_embedding, _, class_labels = data
         dev = torch.device('cuda', self.gpus[0])
         vembedding = t_embedding.float().to(dev, non_blocking=True).requires_grad_()
-        real_vimgs = [imgs[i].to(dev, non_blocking=True) for i in range(self.num_Ds)]
-        wrong_vimgs = [w_imgs[i].to(dev, non_blocking=True) for i in range(self.num_Ds)]
+        def to_dev(t):
+            t = t.to(dev, non_blocking=True)
+            # datasets built with device_normalize=True hand over uint8 HWC batches: ToTensor + Normalize on the GPU
+            return ops.images_from_uint8_hwc(t.contiguous()) if t.dtype == torch.uint8 else t
+        real_vimgs = [to_dev(imgs[i]) for i in range(self.num_Ds)]
+        wrong_vimgs = [to_dev(w_imgs[i]) for i in range(self.num_Ds)]
         return imgs, real_vimgs, wrong_vimgs, vembedding, class_labels
 
     # -- communication ------------------------------------------------------------------------------------------
