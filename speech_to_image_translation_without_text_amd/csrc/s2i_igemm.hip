@@ -565,11 +565,14 @@ struct WgradP {
 };
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM, LDB = BN;
-  constexpr int APASS = BM / 32, BPASS = BN / 32;
-  constexpr int AROWS = 1024 / BM, BROWS = 1024 / BN;
+  constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256, or 192 for the 96-row tiles (K = 9 * 32)
+  constexpr int AROWS = NT * 4 / BM, BROWS = NT * 4 / BN;  // pixel rows of the 32-deep chunk staged per pass
+  static_assert(AROWS * BM == NT * 4 && BROWS * BN == NT * 4, "a pass must cover whole rows");
+  constexpr int APASS = (32 + AROWS - 1) / AROWS, BPASS = (32 + BROWS - 1) / BROWS;
+  constexpr bool APRED = (32 % AROWS) != 0, BPRED = (32 % BROWS) != 0;  // last pass partly beyond the chunk
   __shared__ __attribute__((aligned(16))) float smem[32 * LDA + 32 * LDB];
   float* As = smem;
   float* Bs = smem + 32 * LDA;
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
       const int m = pc * 32 + arow + q * AROWS;
+      if (APRED && arow + q * AROWS >= 32) continue;
       const int b = m >> p.lgHoWo;
       const int r = m & ((1 << p.lgHoWo) - 1);
       const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
@@ -617,6 +621,7 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int m = pc * 32 + brow + q * BROWS;
+      if (BPRED && brow + q * BROWS >= 32) continue;
       rb[q] = bload4(rg_rs, (m < p.M && nvalid) ? m * p.ldg * 4 + gcolb : S2I_OOB);
     }
   };
@@ -635,10 +640,10 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
   for (int pc = c_begin; pc < c_end; ++pc) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q)
-      *reinterpret_cast<f32x4*>(As + (arow + q * AROWS) * LDA + acol4 * 4) = ra[q];
+      if (!APRED || arow + q * AROWS < 32) *reinterpret_cast<f32x4*>(As + (arow + q * AROWS) * LDA + acol4 * 4) = ra[q];
 #pragma unroll
     for (int q = 0; q < BPASS; ++q)
-      *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS) * LDB + bcol4 * 4) = rb[q];
+      if (!BPRED || brow + q * BROWS < 32) *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS) * LDB + bcol4 * 4) = rb[q];
     __syncthreads();
     if (pc + 1 < c_end) fetch(pc + 1);
     mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
@@ -653,6 +658,142 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_kernel(WgradP p) {
     for (int r = 0; r < 16; ++r) {
       const int krow = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (krow >= p.K) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) outp[(size_t)krow * p.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// Weight gradient of a 3x3 stride-1 convolution over a wide map with few channels (the generator at 64x64 and
+// 128x128, Cin = 64 / 32).  The generic kernel above stages an im2col tile per chunk, i.e. it pulls every input pixel
+// through the vector-memory path once per tap; with K x N this small that path, not the matrix cores, is the limit
+// (57-78 TFLOP/s).  Here a block owns ONE kernel row dy and a chunk is 32 consecutive pixels of one image row: the
+// block stages the 34-pixel input row segment (iy = y + dy - 1, halo of one pixel each side) ONCE and the three
+// horizontal taps read their MFMA fragments from it at pixel offsets 0/1/2 -- a third of the loads, no wasted rows
+// (block tile = (3 * CIN) x BN).  Slab rows are (tap, cin) as above, so the slab sum / OIHW finish are shared.
+template <int CIN, int BN, int WAVES_M, int WAVES_N, int DYS>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void wgrad_k3_rows_kernel(WgradP p) {
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = 3 * CIN * DYS, RT = BM / 32;  // DYS = 3: the block owns all three kernel rows (Cin = 32)
+  constexpr int TM = RT / WAVES_M, TN = BN / (32 * WAVES_N);
+  static_assert(TM * WAVES_M == RT && TN * WAVES_N * 32 == BN, "tile split");
+  constexpr int LDH = CIN, LDB = BN;
+  constexpr int CQ = CIN / 4, HQR = 34 * CQ, HQ = DYS * HQR;  // float4 per staged row segment / in total
+  constexpr int HPASS = (HQ + NT - 1) / NT;
+  constexpr int BROWS = NT * 4 / BN, BPASS = (32 + BROWS - 1) / BROWS;
+  static_assert(BROWS * BN == NT * 4, "a pass must cover whole rows");
+  __shared__ __attribute__((aligned(16))) float smem[DYS * 34 * LDH + 32 * LDB];
+  float* Hs = smem;
+  float* Bs = smem + DYS * 34 * LDH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int dy0 = DYS == 3 ? 0 : blockIdx.x, n0 = blockIdx.y * BN, split = blockIdx.z;
+  const int bcol4 = tid % (BN / 4), brow = tid / (BN / 4);
+  const int nb = n0 + bcol4 * 4;
+  const int gcolb = nb < p.N ? nb * 4 : S2I_OOB;
+  const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+
+  f32x4 rh[HPASS], rb[BPASS];
+  auto fetch = [&](int pc) {
+    const int m0 = pc * 32;
+    const int b = m0 >> p.lgHoWo;
+    const int r = m0 & ((1 << p.lgHoWo) - 1);
+    const int y = r >> p.lgWo, x0 = r & (p.W - 1);
+#pragma unroll
+    for (int q = 0; q < HPASS; ++q) {
+      const int e = tid + q * NT;
+      if (e >= HQ) continue;
+      const int dyl = e / HQR, er = e - dyl * HQR;
+      const int iy = y + dy0 + dyl - 1;
+      const int ix = x0 - 1 + er / CQ;
+      const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      rh[q] = bload4(ra_rs, ok ? ((b * p.H + iy) * p.W + x0 - 1) * CIN * 4 + er * 16 : S2I_OOB);
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int row = brow + q * BROWS;
+      if (row >= 32) continue;
+      rb[q] = bload4(rg_rs, gcolb == S2I_OOB ? S2I_OOB : (m0 + row) * p.ldg * 4 + gcolb);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  int aoff[TM];  // row tile -> (horizontal tap, channel half) -> offset inside the halo row segment
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rt = wm * TM + i;                 // row tile -> (kernel row, horizontal tap, channel half)
+    const int dyl = rt / (3 * CIN / 32), rr = rt % (3 * CIN / 32);
+    aoff[i] = dyl * 34 * LDH + (rr / (CIN / 32)) * LDH + (rr % (CIN / 32)) * 32;
+  }
+  const float* hp = Hs + lh * LDH + l31;
+  const float* bp = Bs + lh * LDB + wn * TN * 32 + l31;
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int pc = c_begin; pc < c_end; ++pc) {
+#pragma unroll
+    for (int q = 0; q < HPASS; ++q)
+      if (tid + q * NT < HQ) *reinterpret_cast<f32x4*>(Hs + (tid + q * NT) * 4) = rh[q];
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q)
+      if (brow + q * BROWS < 32) *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS) * LDB + bcol4 * 4) = rb[q];
+    __syncthreads();
+    if (pc + 1 < c_end) fetch(pc + 1);
+    {
+      float a0[TM], b0[TN], a1[TM], b1[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a0[i] = hp[aoff[i]];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b0[j] = bp[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = hp[(2 * (kk + 1)) * LDH + aoff[i]];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b1[j] = bp[(2 * (kk + 1)) * LDB + j * 32];
+        if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+        if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+        if (kk + 2 < 16) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a0[i] = hp[(2 * (kk + 2)) * LDH + aoff[i]];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b0[j] = bp[(2 * (kk + 2)) * LDB + j * 32];
+        }
+        if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+        if constexpr (TM * TN >= 4) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* outp = p.slab + (size_t)split * p.K * p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = dy0 * 3 * CIN + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;  // (dy*3 + dx) * CIN + c
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * TN * 32 + j * 32 + l31;
@@ -909,7 +1050,7 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
 }
 
 struct WgPlan {
-  int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps, small_n;
+  int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps, small_n, rows3, bn3;
 };
 
 int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
@@ -937,8 +1078,10 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   else S2I_REQUIRE(pl->Cin >= d->I && d->N >= d->O, "wgrad: shape mismatch");
   pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
   if (pl->K <= 64 && d->N > 32 && d->N <= 64) pl->tile = 3;  // first discriminator conv: 16 taps x (3+1) channels
-  const int BN = pl->tile == 0 ? 128 : (pl->tile == 2 ? 32 : 64);
-  const int BM = pl->tile == 3 ? 64 : 128;
+  // K = 288 (3x3 taps x 32 channels, the generator's last stage) wastes a quarter of three 128-row tiles: 96-row tiles
+  if (pl->K % 96 == 0 && d->N <= 64 && s2i_cdiv(pl->K, 128) * 128 * 5 > pl->K * 6) pl->tile = d->N > 32 ? 4 : 5;
+  const int BN = pl->tile == 0 ? 128 : ((pl->tile == 2 || pl->tile == 5) ? 32 : 64);
+  const int BM = pl->tile == 3 ? 64 : (pl->tile >= 4 ? 96 : 128);
   pl->gridK = s2i_cdiv(pl->K, BM);
   pl->gridN = s2i_cdiv(d->N, BN);
   pl->nchunks = s2i_cdiv(M, 32);
@@ -950,6 +1093,22 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   if (splitk < 1) splitk = 1;
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  // thin 3x3 layers over wide maps: one kernel row per block, taps read from a staged row segment
+  pl->rows3 = d->kind == S2I_CONV_K3S1 && d->Cc == 0 && (d->Ca == 32 || d->Ca == 64) && d->W >= 32 &&
+              (d->N % 32) == 0 && d->N <= 128;
+  if (pl->rows3) {
+    pl->bn3 = (d->Ca == 64 && d->N > 64) ? 128 : (d->N > 32 ? 64 : 32);
+    pl->gridN = s2i_cdiv(d->N, pl->bn3);
+    // measured (24x128x128, 32->64): 512 / 768 / 1024 / 1536 blocks = 211 / 202 / 183 / 234 us; four 192-thread blocks or
+    // three 256-thread blocks fill a CU, more only adds slab traffic
+    const int target = d->Ca == 32 ? 1024 : 768;
+    int sk = target / ((d->Ca == 32 ? 1 : 3) * pl->gridN);
+    if (sk > pl->nchunks / 4) sk = pl->nchunks / 4;
+    if (sk > 2048) sk = 2048;
+    if (sk < 1) sk = 1;
+    pl->cps = s2i_cdiv(pl->nchunks, sk);
+    pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  }
   // <= 4 output channels of a 3x3 conv: streamed on the vector units, one slab per block
   pl->small_n = d->kind == S2I_CONV_K3S1 && d->Cc == 0 && d->N == 4 && d->ldg == 4 &&
                 (d->Ca == 16 || d->Ca == 32 || d->Ca == 64) && d->W >= 16 && M >= (1 << 15);
@@ -1103,14 +1262,23 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
-  if (pl.small_n) {
+  if (pl.rows3) {
+    dim3 g3(d->Ca == 32 ? 1 : 3, pl.gridN, pl.splitk);
+    if (d->Ca == 32 && pl.bn3 == 64) hipLaunchKernelGGL((wgrad_k3_rows_kernel<32, 64, 3, 1, 3>), g3, dim3(192), 0, st, p);
+    else if (d->Ca == 32) hipLaunchKernelGGL((wgrad_k3_rows_kernel<32, 32, 3, 1, 3>), g3, dim3(192), 0, st, p);
+    else if (pl.bn3 == 128) hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 128, 2, 2, 1>), g3, dim3(256), 0, st, p);
+    else if (pl.bn3 == 64) hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 64, 2, 2, 1>), g3, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 32, 2, 1, 1>), g3, dim3(128), 0, st, p);
+  } else if (pl.small_n) {
     if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(small_n_wgrad_kernel<16>, dim3(pl.splitk), dim3(256), 0, st, p);
   } else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (pl.tile == 3) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);
+  else if (pl.tile == 4) hipLaunchKernelGGL((igemm_wgrad_kernel<96, 64, 3, 1>), grid, dim3(192), 0, st, p);
+  else hipLaunchKernelGGL((igemm_wgrad_kernel<96, 32, 3, 1>), grid, dim3(192), 0, st, p);
   S2I_LAUNCH_CHECK("igemm_wgrad");
   {
     const int ncols = d->swap ? d->I : d->O, nrows = d->swap ? d->O : d->I;
@@ -1122,7 +1290,8 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     // float4 stream folds the split slabs into slab 0, then the tile kernel transposes slab 0 into OIHW
     int S = pl.splitk;
     const long long kn = (long long)pl.K * d->N;
-    if (pl.small_n) {
+    if (pl.small_n || (S >= 32 && (kn % 4) == 0 && kn / 4 < (1 << 18))) {
+      // many slabs of a small K x N: the float4 stream below would run on a handful of blocks
       hipLaunchKernelGGL(slab_sum_tree_kernel, dim3(s2i_cdiv(kn / 4, 4)), dim3(256), 0, st, (float*)ws, S, (int)(kn / 4));
       S2I_LAUNCH_CHECK("slab_sum_tree");
       S = 1;

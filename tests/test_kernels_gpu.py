@@ -79,6 +79,13 @@ CASES = [
     ("up", 2, 32, 8, 0, 8, "glu", False),
     ("k1", 4, 1, 12, 16, 64, "glu", False),        # INIT_STAGE_G.fc: cat(c_code, z) -> Linear -> BN1d -> GLU
     ("k3s1", 2, 64, 8, 0, 8, "glu", False),        # many row tiles -> multi-part statistics
+    ("k3s1", 2, 16, 32, 0, 64, "glu", False),      # K = 9 x 32 = 288: weight gradient on 96-row tiles (96x64)
+    ("k3s1", 2, 16, 32, 0, 32, "none", True),      # ... 96x32
+    ("k3s1", 2, 32, 32, 0, 32, "none", True),      # wide map, thin layer: row-segment weight gradient <32,32>
+    ("k3s1", 3, 64, 32, 0, 64, "glu", False),      # ... <32,64>
+    ("k3s1", 2, 32, 64, 0, 128, "glu", False),     # ... <64,128>
+    ("k3s1", 2, 32, 64, 0, 64, "none", True),      # ... <64,64>
+    ("k3s1", 2, 32, 64, 0, 32, "none", False),     # ... <64,32>
     # full-width D64 layers at batch 4 (BASELINE config 1 shapes)
     ("k4s2", 4, 32, 64, 0, 128, "lrelu", False),
     ("k4s2", 4, 16, 128, 0, 256, "lrelu", False),
