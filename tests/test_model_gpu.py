@@ -454,3 +454,67 @@ def test_colour_consistency_loss_term(gpu):
     expect = float(term(-1, -2) + term(-2, -3))
     # both G losses were taken against the same (frozen, lr=0) networks apart from BatchNorm running statistics
     assert abs((float(with_colour) - float(base)) - expect) <= 2e-3 * max(1.0, abs(expect)) + 1e-3
+
+
+def test_full_size_step_is_bitwise_reproducible(gpu):
+    """BASELINE config 2 at full size: no kernel uses atomics and the discriminator streams only reorder independent
+    work, so two runs of three iterations from the same seeded state end in bit-identical parameters, Adam state,
+    running statistics and losses."""
+    from speech_to_image_translation_without_text_amd import trainer as T
+    case = dict(CASES['full3_fwd'], B=24)
+    batch = make_batch(case)
+    finals = []
+    for _ in range(2):
+        netG, netsD = build_nets(case)
+        netG.to(gpu)
+        for d in netsD:
+            d.to(gpu)
+        tr = T.condGANTrainer(None, None, 256, False)
+        tr.build(netG, netsD)
+        b = to_dev(batch, gpu)
+        losses = []
+        for it in range(3):
+            g = torch.Generator(device=gpu).manual_seed(100 + it)
+            noise = torch.randn(b['noise'].shape, device=gpu, generator=g)
+            eps = torch.randn(b['eps'].shape, device=gpu, generator=g)
+            out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], noise, eps)
+            losses.append(torch.stack([o.detach().reshape(()) for o in out]))
+        torch.cuda.synchronize()
+        state = [tr.flatG.p.clone(), tr.flatG.m.clone(), tr.flatG.v.clone()] + [f.p.clone() for f in tr.flatsD]
+        state += [netsD[2].state_dict()['img_code_s64_2.1.running_var'].clone(), torch.stack(losses)]
+        finals.append(state)
+        del tr, netG, netsD
+    for a, c in zip(*finals):
+        assert torch.equal(a, c)
+
+
+def test_full_size_conv_properties(gpu):
+    """Size-independent properties at BASELINE config 2's layer sizes (the oracle is too slow to be the checker there):
+    linearity of the conv in its input, and <conv(x), g> = <w, wgrad(x, g)> = <x, dgrad(g)> (the three GEMMs are
+    adjoint views of one trilinear form) for D_NET256's Conv2d(64,128,k4,s2,p1) on a stacked (72,128,128,64) input and
+    the generator's 3x3 (24,128,128,32) -> 64 layer (row-segment weight gradient)."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K3S1, CONV_K4S2, TCONV_K4S2
+    g = torch.Generator(device=gpu).manual_seed(5)
+    for kind, B, H, Cin, Cout, kk in ((CONV_K4S2, 72, 128, 64, 128, 4), (CONV_K3S1, 24, 128, 32, 64, 3)):
+        Ho = H // 2 if kind == CONV_K4S2 else H
+        x = torch.randn(B, H, H, Cin, device=gpu, generator=g)
+        x2 = torch.randn(B, H, H, Cin, device=gpu, generator=g)
+        w = torch.randn(Cout, Cin, kk, kk, device=gpu, generator=g) * 0.05
+        gy = torch.randn(B, Ho, Ho, Cout, device=gpu, generator=g)
+        packed = ops.pack_weight(w, ops.PACK_PLAIN)
+        conv = lambda t: ops.conv_raw(kind, t, None, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2])[0]
+        y, y2 = conv(x), conv(x2)
+        ylin = conv(2.0 * x - 3.0 * x2)
+        scale = float(y.abs().max())
+        assert float((ylin - (2.0 * y - 3.0 * y2)).abs().max()) <= 2e-5 * scale * 5
+        dw = ops.wgrad_raw(kind, x, None, gy, tuple(w.shape))
+        if kind == CONV_K4S2:
+            dx = ops.conv_raw(TCONV_K4S2, gy, None, packed, Cin, wmode=1, wR=packed.shape[1], ldw=packed.shape[2])[0]
+        else:
+            dx = ops.conv_raw(CONV_K3S1, gy, None, packed, Cin, wmode=1, flip=1, wR=packed.shape[1], ldw=packed.shape[2])[0]
+        a = float((y.double() * gy.double()).sum())
+        b_ = float((w.double() * dw.double()).sum())
+        c = float((x.double() * dx.double()).sum())
+        ref = float((y.double().abs() * gy.double().abs()).sum())  # scale of the cancellation
+        assert abs(a - b_) <= 1e-6 * ref and abs(a - c) <= 1e-6 * ref, (a, b_, c, ref)
