@@ -39,6 +39,10 @@ struct IgemmP {
   int wt;                // weights read transposed per tap (small_n_conv_kernel; the igemm takes it as a template flag)
   unsigned x_bytes, c_bytes, w_bytes;
   long long Mrows;
+  // split-bf16 weights [plane][tap][n][k] (igemm_fwd_split_kernel)
+  const unsigned short* __restrict__ wsp;
+  int wsp_np, wsp_kp, wsp_plane;  // rows per tap, row length (bf16 elements), elements per plane
+  unsigned wsp_bytes;
 };
 
 __device__ __forceinline__ void geom(const IgemmP& p, int kind, int& s, int& pad, int& kw) {
@@ -418,6 +422,303 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant ("bf16xNP" math modes): every fp32 operand value v is written as the sum of NP bf16 numbers
+// (v1 = bf16(v), v2 = bf16(v - v1), v3 = bf16(v - v1 - v2)) and the products a_i * b_j with i + j <= NP + 1 are
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, which runs at 16x the rate of v_mfma_f32_32x32x2_f32.
+//   NP = 2: 3 products, relative product error ~2^-16 (TF32, which the reference's cuDNN convolutions use by default on
+//           NVIDIA hardware, is 2^-11);   NP = 3: 6 products, ~2^-23.
+// Activations are split while they are staged into LDS (v_cvt_pk_bf16_f32 + two VALU ops per extra plane and pair);
+// weights arrive pre-split in [plane][tap][n][k] order (s2i_split_packed_weight), so a B tile is a straight 16-byte copy.
+// LDS: one [rows][32 k] bf16 image per plane and operand, 64-byte rows whose four 16-byte segments are XOR-swizzled
+// with (row >> 2) & 3: a fragment is ONE ds_read_b128 per lane (row r = lane & 31, k = 8 * (lane >> 5) + j) and 16
+// consecutive rows hit 16 distinct 4-bank groups; three planes of a 128x128 tile take 48 KB, so three blocks fit a CU.
+// Gather, split-K, epilogue and statistics are those of igemm_fwd_kernel (CA32 case only).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+template <int NP>
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&out)[NP]) {
+  f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+#pragma unroll
+  for (int pl = 0; pl < NP; ++pl) {
+    const unsigned pa = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+    const unsigned pb = __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2));
+    out[pl] = u32x2{pa, pb};
+    if (pl + 1 < NP) {
+      a[0] -= __builtin_bit_cast(float, pa << 16);
+      a[1] -= __builtin_bit_cast(float, pa & 0xffff0000u);
+      b[0] -= __builtin_bit_cast(float, pb << 16);
+      b[1] -= __builtin_bit_cast(float, pb & 0xffff0000u);
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP>
+__global__ __launch_bounds__(256, 3) void igemm_fwd_split_kernel(IgemmP p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int ROWB = 64;
+  constexpr int APLANE = BM * ROWB, BPLANE = BN * ROWB;
+  constexpr int ASLOTS = BM / 32;
+  constexpr int BSEGS = NP * BN * 4;                 // 16-byte segments of the B tile
+  constexpr int BLOADS = (BSEGS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + BPLANE)];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + NP * APLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int phase = 0, split = blockIdx.z;
+  if (p.kind == S2I_TCONV_K4S2) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  const int py = phase >> 1, px = phase & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kq = tid & 7, mrow = tid >> 3;
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)p.cvec, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.wsp, 0, p.wsp_bytes, 0x00020000);
+
+  int aoff[ASLOTS];
+  unsigned amask[ASLOTS];
+  int acoff[ASLOTS];
+#pragma unroll
+  for (int i = 0; i < ASLOTS; ++i) {
+    const int m = m0 + mrow + 32 * i;
+    unsigned mask = 0;
+    int base = 0, coff = 0;
+    if (m < p.M) {
+      const int b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+      const int by = p.kind == S2I_CONV_1D ? oy : oy * s - pad, bx = ox * s - pad;
+      mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
+      base = (((b * p.H + by) * p.W + bx) * p.Cx + kq * 4) * 4;
+      coff = (b * p.Cc + kq * 4) * 4;
+    }
+    aoff[i] = base;
+    amask[i] = mask;
+    acoff[i] = coff;
+  }
+  int bconst[BLOADS], blds[BLOADS];
+#pragma unroll
+  for (int q = 0; q < BLOADS; ++q) {
+    const int e = tid + q * 256;
+    const int seg = e & 3, row = (e >> 2) % BN, pl = (e >> 2) / BN;
+    const int n = n0 + row;
+    bconst[q] = (e < BSEGS && n < p.N) ? (pl * p.wsp_plane + n * p.wsp_kp) * 2 + seg * 16 : S2I_OOB;
+    blds[q] = e < BSEGS ? pl * BPLANE + row * ROWB + ((seg ^ ((row >> 2) & 3)) << 4) : -1;
+  }
+
+  f32x4 ra[ASLOTS];
+  u32x4 rb[BLOADS];
+  auto fetch = [&](int kc) {
+    const int k0 = kc * 32;
+    const int t = k0 / p.Ca;
+    const int c0 = k0 - t * p.Ca;
+    int dy, dx;
+    tap_delta(p.kind, kw, t, py, px, dy, dx);
+    const int tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+    if (c0 < p.Cc) {
+#pragma unroll
+      for (int i = 0; i < ASLOTS; ++i)
+        ra[i] = bload4(rc, ((amask[i] >> t) & 1u) ? acoff[i] + c0 * 4 : S2I_OOB);
+    } else {
+      const int toff = ((dy * p.W + dx) * p.Cx + (c0 - p.Cc)) * 4;
+#pragma unroll
+      for (int i = 0; i < ASLOTS; ++i)
+        ra[i] = bload4(rx, ((amask[i] >> t) & 1u) ? aoff[i] + toff : S2I_OOB);
+    }
+    const int wbase = (tw * p.wsp_np * p.wsp_kp + c0) * 2;
+#pragma unroll
+    for (int q = 0; q < BLOADS; ++q)
+      rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, bconst[q] == S2I_OOB ? S2I_OOB : wbase + bconst[q], 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int fsw = ((lh ^ ((l31 >> 2) & 3)) << 4);  // swizzled segment of k-step 0; k-step 1 is fsw ^ 32
+  const unsigned char* ap = As + (wm * TM * 32 + l31) * ROWB;
+  const unsigned char* bp = Bs + (wn * TN * 32 + l31) * ROWB;
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int kc = c_begin; kc < c_end; ++kc) {
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+      u32x2 sp[NP];
+      split4<NP>(ra[i], sp);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x2*>(As + pl * APLANE + (mrow + 32 * i) * ROWB + ((((kq >> 1) ^ (mrow >> 2)) & 3) << 4) +
+                                  (kq & 1) * 8) = sp[pl];
+    }
+#pragma unroll
+    for (int q = 0; q < BLOADS; ++q)
+      if (blds[q] >= 0) *reinterpret_cast<u32x4*>(Bs + blds[q]) = rb[q];
+    __syncthreads();
+    if (kc + 1 < c_end) fetch(kc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int so = fsw ^ (ks << 5);
+      bf16x8 a[NP][TM];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[pl][i] = *reinterpret_cast<const bf16x8*>(ap + pl * APLANE + i * 32 * ROWB + so);
+      // b plane by plane, the smallest cross terms first: (a1 b3) | (a2 b2, a1 b2) | (a3 b1, a2 b1, a1 b1)
+#pragma unroll
+      for (int pb = NP - 1; pb >= 0; --pb) {
+        bf16x8 b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(bp + pb * BPLANE + j * 32 * ROWB + so);
+#pragma unroll
+        for (int pa = NP - 1 - pb; pa >= 0; --pa)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (as igemm_fwd_kernel) ----
+  const bool tconv = p.kind == S2I_TCONV_K4S2;
+  const bool raw = p.splitk > 1;
+  if (p.cls_bias && !raw) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        const int b = m >> p.lgHoWo;
+        const int rr = m & ((1 << p.lgHoWo) - 1);
+        const int oy = rr >> p.lgWo, ox = rr & (p.Wo - 1);
+        const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+        const float* bpt = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) acc[i][j][r] += bpt[n];
+        }
+      }
+  }
+  float* outp = raw ? p.slab + (size_t)split * p.Mrows * p.N : p.y;
+  const int ldo = raw ? p.N : p.ldy;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      long long row = m;
+      if (tconv) {
+        const int b = m >> p.lgHoWo;
+        const int rr = m & ((1 << p.lgHoWo) - 1);
+        const int oy = rr >> p.lgWo, ox = rr & (p.Wo - 1);
+        row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) {
+          float v = acc[i][j][r];
+          if (!raw) {
+            if (p.bias) v += p.bias[n];
+            if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+            else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+            else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+          }
+          outp[row * ldo + n] = v;
+        }
+      }
+    }
+  }
+  if (p.stats && !raw) {
+    float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          sv += v;
+          sq += v * v;
+        }
+      sv += __shfl_xor(sv, 32);
+      sq += __shfl_xor(sq, 32);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + j * 32 + l31;
+        red[(0 * WAVES_M + wm) * BN + col] = sv;
+        red[(1 * WAVES_M + wm) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.N) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES_M; ++q) {
+          sv += red[(0 * WAVES_M + q) * BN + tid];
+          sq += red[(1 * WAVES_M + q) * BN + tid];
+        }
+        const int gm = phase * gridDim.x + blockIdx.x;
+        p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
+        p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
+      }
+    }
+  }
+}
+
+// fp32 packed weights P[T][R][C] -> NP bf16 planes, [plane][T][R][C] (transpose = 0) or [plane][T][C][R] (transpose = 1)
+__global__ __launch_bounds__(256) void split_packed_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                           int R, int C, int NP, int transpose, long long plane) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float* sp = src + (size_t)t * R * C;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + 8 * k, c = c0 + tx;
+    tile[ty + 8 * k][tx] = (r < R && c < C) ? sp[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int orow, ocol;
+    float v;
+    if (transpose) { orow = c0 + ty + 8 * k; ocol = r0 + tx; v = tile[tx][ty + 8 * k]; if (orow >= C || ocol >= R) continue; }
+    else { orow = r0 + ty + 8 * k; ocol = c0 + tx; v = tile[ty + 8 * k][tx]; if (orow >= R || ocol >= C) continue; }
+    const size_t o = transpose ? ((size_t)t * C + orow) * R + ocol : ((size_t)t * R + orow) * C + ocol;
+    for (int pl = 0; pl < NP; ++pl) {
+      const __bf16 h = (__bf16)v;
+      dst[pl * plane + o] = __builtin_bit_cast(unsigned short, h);
+      v -= (float)h;
+    }
+  }
+}
+
 // Convolutions with at most 4 output channels (GET_IMAGE_G's conv3x3 -> RGB, model.py:287-298, and the input
 // gradient of the discriminators' first conv): HBM-bound, so no matrix cores.  LPP = Ca/4 lanes share one output
 // pixel, each multiplying its 4 input channels into the 4 outputs (weights [t][c][4] in LDS), then a shuffle
@@ -647,6 +948,177 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
     __syncthreads();
     if (pc + 1 < c_end) fetch(pc + 1);
     mma_chunk<TM, TN, LDA, LDB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+    __syncthreads();
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* outp = p.slab + (size_t)split * p.K * p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (krow >= p.K) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) outp[(size_t)krow * p.N + n] = acc[i][j][r];
+      }
+    }
+}
+
+// Split-bf16 weight gradient (see igemm_fwd_split_kernel).  The reduction index of this GEMM is the pixel, and both
+// operands arrive pixel-major (NHWC), so the LDS images stay [pixel][row] -- a staged float4 becomes one 8-byte write per
+// plane -- and the MFMA fragments (8 consecutive PIXELS of one row per lane) are fetched with the transposing read
+// ds_read_b64_tr_b16: per 16-lane group it takes a 4-pixel x 16-row block and hands lane i column i.  16-byte chunks
+// of a pixel row are XOR-swizzled with ((pixel & 3) << 2) | ((pixel >> 2) & 3) (cdna_hip_programming.md T10, image (b)).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ s16x4 lds_tr_read(const unsigned char* ptr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(ptr));
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NP>
+__global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int AROWB = BM * 2, BROWB = BN * 2;
+  constexpr int APLANE = 32 * AROWB, BPLANE = 32 * BROWB;
+  constexpr int AMASK = BM / 8 - 1, BMASK = BN / 8 - 1;
+  constexpr int APASS = BM / 32, BPASS = BN / 32;
+  constexpr int AROWS = 1024 / BM, BROWS = 1024 / BN;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (APLANE + BPLANE)];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + NP * APLANE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  int s, pad, kw;
+  geom(p.kind, s, pad, kw);
+
+  const int acol4 = tid % (BM / 4), arow = tid / (BM / 4);
+  const int bcol4 = tid % (BN / 4), brow = tid / (BN / 4);
+  const int kcol = k0 + acol4 * 4;
+  const bool kvalid = kcol < p.K;
+  int c = 0, dy = 0, dx = 0;
+  if (kvalid) {
+    const int t = kcol / p.Cin;
+    c = kcol - t * p.Cin;
+    dy = t / kw;
+    dx = t - dy * kw;
+  }
+  const bool from_vec = c < p.Cc;
+  const int nb = n0 + bcol4 * 4;
+  const bool nvalid = nb < p.N;
+  const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.cvec, 0, p.c_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  const int acolb = (c - p.Cc) * 4;
+  const int ccolb = c * 4;
+  const int gcolb = nvalid ? nb * 4 : S2I_OOB;
+  f32x4 ra[APASS], rb[BPASS];
+  auto fetch = [&](int pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      const int m = pc * 32 + arow + q * AROWS;
+      const int b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+      const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+      const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      if (from_vec) ra[q] = bload4(rc_rs, ok ? b * p.Cc * 4 + ccolb : S2I_OOB);
+      else ra[q] = bload4(ra_rs, ok ? ((b * p.H + iy) * p.W + ix) * p.Ca * 4 + acolb : S2I_OOB);
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int m = pc * 32 + brow + q * BROWS;
+      rb[q] = bload4(rg_rs, (m < p.M && nvalid) ? m * p.ldg * 4 + gcolb : S2I_OOB);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // transposed-read addressing of this lane (see header): group g = lane >> 4 -> (h = g >> 1, 16-row block g & 1)
+  const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+  const int gh = lane >> 5, gcb = (lane >> 4) & 1;
+  const int sw0 = (gq << 2) | (2 * gh);              // swizzle of pixel rows 8h + q (+ 16 ks); rows + 4: sw0 | 1
+  int aad[TM][2], bad[TN][2];                        // byte offsets inside a plane for the two 4-pixel half fragments
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int prow = 8 * gh + 4 * f + gq;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ch = ((wm * TM + i) * 32 + 16 * gcb) / 8 + (gp >> 1);
+      aad[i][f] = prow * AROWB + 16 * ((ch ^ (sw0 | f)) & AMASK) + 8 * (gp & 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ch = ((wn * TN + j) * 32 + 16 * gcb) / 8 + (gp >> 1);
+      bad[j][f] = prow * BROWB + 16 * ((ch ^ (sw0 | f)) & BMASK) + 8 * (gp & 1);
+    }
+  }
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int pc = c_begin; pc < c_end; ++pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      const int row = arow + q * AROWS;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+      u32x2 sp[NP];
+      split4<NP>(ra[q], sp);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x2*>(As + pl * APLANE + row * AROWB + 16 * (((acol4 >> 1) ^ sw) & AMASK) + 8 * (acol4 & 1)) = sp[pl];
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int row = brow + q * BROWS;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+      u32x2 sp[NP];
+      split4<NP>(rb[q], sp);
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+        *reinterpret_cast<u32x2*>(Bs + pl * BPLANE + row * BROWB + 16 * (((bcol4 >> 1) ^ sw) & BMASK) + 8 * (bcol4 & 1)) = sp[pl];
+    }
+    __syncthreads();
+    if (pc + 1 < c_end) fetch(pc + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[NP][TM];
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const s16x4 lo = lds_tr_read(As + pl * APLANE + ks * 16 * AROWB + aad[i][0]);
+          const s16x4 hi = lds_tr_read(As + pl * APLANE + ks * 16 * AROWB + aad[i][1]);
+          a[pl][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+      for (int pb = NP - 1; pb >= 0; --pb) {
+        bf16x8 b[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const s16x4 lo = lds_tr_read(Bs + pb * BPLANE + ks * 16 * BROWB + bad[j][0]);
+          const s16x4 hi = lds_tr_read(Bs + pb * BPLANE + ks * 16 * BROWB + bad[j][1]);
+          b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+#pragma unroll
+        for (int pa = NP - 1 - pb; pa >= 0; --pa)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa][i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
     __syncthreads();
   }
 
@@ -1053,7 +1525,7 @@ struct WgPlan {
   int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps, small_n, rows3, bn3;
 };
 
-int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
+int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
   S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "wgrad: non-positive extent");
   S2I_REQUIRE((d->Ca % 4) == 0 && (d->Cc % 4) == 0 && (d->N % 4) == 0 && d->Ca + d->Cc > 0,
               "wgrad: channel counts must be multiples of 4 (Ca=%d Cc=%d N=%d)", d->Ca, d->Cc, d->N);
@@ -1079,7 +1551,7 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
   if (pl->K <= 64 && d->N > 32 && d->N <= 64) pl->tile = 3;  // first discriminator conv: 16 taps x (3+1) channels
   // K = 288 (3x3 taps x 32 channels, the generator's last stage) wastes a quarter of three 128-row tiles: 96-row tiles
-  if (pl->K % 96 == 0 && d->N <= 64 && s2i_cdiv(pl->K, 128) * 128 * 5 > pl->K * 6) pl->tile = d->N > 32 ? 4 : 5;
+  if (!planes && pl->K % 96 == 0 && d->N <= 64 && s2i_cdiv(pl->K, 128) * 128 * 5 > pl->K * 6) pl->tile = d->N > 32 ? 4 : 5;
   const int BN = pl->tile == 0 ? 128 : ((pl->tile == 2 || pl->tile == 5) ? 32 : 64);
   const int BM = pl->tile == 3 ? 64 : (pl->tile >= 4 ? 96 : 128);
   pl->gridK = s2i_cdiv(pl->K, BM);
@@ -1094,7 +1566,7 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl) {
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
   // thin 3x3 layers over wide maps: one kernel row per block, taps read from a staged row segment
-  pl->rows3 = d->kind == S2I_CONV_K3S1 && d->Cc == 0 && (d->Ca == 32 || d->Ca == 64) && d->W >= 32 &&
+  pl->rows3 = !planes && d->kind == S2I_CONV_K3S1 && d->Cc == 0 && (d->Ca == 32 || d->Ca == 64) && d->W >= 32 &&
               (d->N % 32) == 0 && d->N <= 128;
   if (pl->rows3) {
     pl->bn3 = (d->Ca == 64 && d->N > 64) ? 128 : (d->N > 32 ? 64 : 32);
@@ -1159,15 +1631,60 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
   return s2i_conv_forward_cls(d, x, cvec, w, bias, nullptr, y, part, ws, ws_bytes, stream);
 }
 
+static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                             const unsigned short* wsp, int planes, int np, int kp, const float* bias,
+                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                                     const float* bias, const float* cls_bias, float* y, float* part, void* ws,
                                     size_t ws_bytes, void* stream) {
+  S2I_REQUIRE(w != nullptr, "conv: null weight");
+  return conv_forward_impl(d, x, cvec, w, nullptr, 0, 0, 0, bias, cls_bias, y, part, ws, ws_bytes, stream);
+}
+
+extern "C" int s2i_conv_split_eligible(const s2i_conv_desc* d) {
+  FwdPlan pl;
+  if (plan_fwd(d, &pl)) return 0;
+  const bool small_n = d->N <= 4 && d->Cc == 0 && !d->stats && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
+                       (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) && pl.M >= 4096;
+  return (pl.Ca % 32) == 0 && (d->Cc % 32) == 0 && !small_n;
+}
+
+extern "C" int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, const float* cvec,
+                                      const unsigned short* wsplit, int planes, int np, int kp, const float* bias,
+                                      const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes,
+                                      void* stream) {
+  S2I_REQUIRE(wsplit != nullptr && (planes == 2 || planes == 3), "conv(split): need 2 or 3 bf16 planes");
+  S2I_REQUIRE(np > 0 && kp > 0 && (kp % 8) == 0, "conv(split): weight rows must be multiples of 8 bf16 (kp=%d)", kp);
+  S2I_REQUIRE(s2i_conv_split_eligible(d), "conv(split): layer not eligible (gathered channels must be multiples of 32)");
+  return conv_forward_impl(d, x, cvec, nullptr, wsplit, planes, np, kp, bias, cls_bias, y, part, ws, ws_bytes, stream);
+}
+
+extern "C" int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, int transpose,
+                                       unsigned short* out, void* stream) {
+  S2I_REQUIRE(packed && out && T > 0 && R > 0 && C > 0 && (planes == 2 || planes == 3), "split_packed_weight: bad args");
+  dim3 grid(s2i_cdiv(C, 32), s2i_cdiv(R, 32), T);
+  hipLaunchKernelGGL(split_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, packed, out, R, C, planes, transpose,
+                     (long long)T * R * C);
+  S2I_LAUNCH_CHECK("split_packed_weight");
+  return 0;
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_split(const IgemmP& p, dim3 grid, int planes, hipStream_t st) {
+  if (planes == 2) hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, p);
+}
+
+static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
+                             const unsigned short* wsp, int planes, int np, int kp, const float* bias,
+                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 1;
   S2I_REQUIRE(!cls_bias || (d->kind == S2I_CONV_K3S1 && pl.splitk == 1), "conv: class bias needs an unsplit 3x3 conv");
   S2I_REQUIRE(x != nullptr || d->Cx == 0, "conv: x is null");
   S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "conv: cvec is null but Cc > 0");
-  S2I_REQUIRE(w && y, "conv: null weight/output");
+  S2I_REQUIRE((w || wsp) && y, "conv: null weight/output");
   S2I_REQUIRE(!d->stats || part, "conv: stats requested without a partial buffer");
   const size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
   S2I_REQUIRE(ws_bytes >= need && (need == 0 || ws), "conv: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1182,7 +1699,8 @@ extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, cons
   p.ldw = d->ldw; p.wR = d->wR; p.ldy = d->ldy; p.nparts = pl.gridM * pl.nphases;
   p.g_kw = d->kw; p.g_s = d->stride; p.g_pad = d->pad; p.wt = d->wmode != 0;
   p.Mrows = pl.Mrows;
-  if (d->N <= 4 && d->Cc == 0 && !d->stats && !cls_bias && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
+  p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
+  if (!wsp && d->N <= 4 && d->Cc == 0 && !d->stats && !cls_bias && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
       (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) && pl.M >= 4096) {
     // HBM-bound RGB-sized layers: VALU kernel instead of a 32-wide MFMA tile that is 7/8 padding
     p.wt = d->wmode != 0;
@@ -1205,10 +1723,22 @@ extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, cons
   p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   p.w_bytes = (unsigned)wb;
   const bool ca32 = (pl.Ca % 32) == 0 && (d->Cc % 32) == 0;
-  if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, ca32, st);
-  else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, ca32, st);
-  else launch_fwd<128, 32, 4, 1>(p, grid, wt, ca32, st);
-  S2I_LAUNCH_CHECK("igemm_fwd");
+  if (wsp) {
+    const unsigned long long pe = (unsigned long long)wtaps * np * kp;  // elements per plane
+    S2I_REQUIRE(pe * planes * 2ull < 0x7ff00000ull, "conv(split): weight planes exceed the buffer window");
+    S2I_REQUIRE(kp >= pl.Ca && np >= d->N, "conv(split): weight planes %d x %d too small for N=%d K=%d", np, kp, d->N, pl.Ca);
+    p.wsp_plane = (int)pe;
+    p.wsp_bytes = (unsigned)(pe * planes * 2ull);
+    if (pl.tile == 0) launch_split<128, 128, 2, 2>(p, grid, planes, st);
+    else if (pl.tile == 1) launch_split<128, 64, 2, 2>(p, grid, planes, st);
+    else launch_split<128, 32, 4, 1>(p, grid, planes, st);
+    S2I_LAUNCH_CHECK("igemm_fwd_split");
+  } else {
+    if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, ca32, st);
+    else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, ca32, st);
+    else launch_fwd<128, 32, 4, 1>(p, grid, wt, ca32, st);
+    S2I_LAUNCH_CHECK("igemm_fwd");
+  }
   if (pl.splitk > 1) {
     if (d->stats && (d->N % 4) == 0 && (d->ldy % 4) == 0) {
       const int Q = d->N / 4;
@@ -1239,10 +1769,36 @@ extern "C" size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d) {
   return (size_t)pl.splitk * pl.K * d->N * sizeof(float);
 }
 
+static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
                               float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  return conv_wgrad_impl(d, 0, a, cvec, g, grad_oihw, ws, ws_bytes, stream);
+}
+
+extern "C" size_t s2i_wgrad_workspace_bytes_split(const s2i_wgrad_desc* d, int planes) {
   WgPlan pl;
-  if (plan_wgrad(d, &pl)) return 1;
+  if (plan_wgrad(d, &pl, planes)) return 0;
+  return (size_t)pl.splitk * pl.K * d->N * sizeof(float);
+}
+
+extern "C" int s2i_conv_wgrad_split(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec,
+                                    const float* g, float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  S2I_REQUIRE(planes == 2 || planes == 3, "wgrad(split): need 2 or 3 bf16 planes");
+  return conv_wgrad_impl(d, planes, a, cvec, g, grad_oihw, ws, ws_bytes, stream);
+}
+
+template <int BM, int BN, int WM, int WN>
+static void launch_wgrad_split(const WgradP& p, dim3 grid, int planes, hipStream_t st) {
+  if (planes == 2) hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, p);
+}
+
+static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  WgPlan pl;
+  if (plan_wgrad(d, &pl, planes)) return 1;
   S2I_REQUIRE((a || d->Ca == 0) && g && grad_oihw, "wgrad: null operand");
   S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "wgrad: cvec is null but Cc > 0");
   const size_t need = (size_t)pl.splitk * pl.K * d->N * sizeof(float);
@@ -1269,6 +1825,11 @@ extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const flo
     else if (pl.bn3 == 128) hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 128, 2, 2, 1>), g3, dim3(256), 0, st, p);
     else if (pl.bn3 == 64) hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 64, 2, 2, 1>), g3, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((wgrad_k3_rows_kernel<64, 32, 2, 1, 1>), g3, dim3(128), 0, st, p);
+  } else if (planes && !pl.small_n) {
+    if (pl.tile == 0) launch_wgrad_split<128, 128, 2, 2>(p, grid, planes, st);
+    else if (pl.tile == 1) launch_wgrad_split<128, 64, 2, 2>(p, grid, planes, st);
+    else if (pl.tile == 2) launch_wgrad_split<128, 32, 4, 1>(p, grid, planes, st);
+    else launch_wgrad_split<64, 64, 2, 2>(p, grid, planes, st);
   } else if (pl.small_n) {
     if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);

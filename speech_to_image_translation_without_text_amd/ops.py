@@ -16,6 +16,7 @@ Activations between these ops are NHWC; parameters stay in the reference's OIHW 
 re-packed to the kernels' layout when their version counter changes.  There is no CPU fallback.
 """
 import ctypes
+import os
 
 import torch
 
@@ -141,6 +142,32 @@ def pack_weight(w, mode, out=None):
     if out is None or out.numel() != T * Ip * Op:
         out = torch.empty((T, Ip, Op), dtype=torch.float32, device=w.device)
     check(lib.s2i_pack_conv_weight(ptr(w), ptr(out), O, I, KH, KW, Ip, mode, stream()), "s2i_pack_conv_weight")
+    out._s2i_gen = getattr(out, '_s2i_gen', 0) + 1  # invalidates the split-bf16 copies derived from it
+    return out
+
+
+# Matrix-product mode of the convolution GEMMs: 0 = native fp32 MFMA (default); 2 / 3 = operands split into that many
+# bf16 planes (include/s2i_hip.h, "split-bf16 matrix products").  Opt-in: S2I_MATH_PLANES=2|3.
+MATH_PLANES = int(os.environ.get("S2I_MATH_PLANES", "0"))
+
+
+def split_weight(packed, planes, transpose):
+    """bf16 planes of a packed weight tensor P[T][R][C], cached on the tensor object until it is re-packed."""
+    lib = _lib_ready()
+    cache = getattr(packed, '_s2i_split', None)
+    if cache is None:
+        cache = {}
+        packed._s2i_split = cache
+    gen = packed._s2i_gen
+    ent = cache.get((planes, transpose))
+    if ent is not None and ent[1] == gen:
+        return ent[0]
+    T, R, C = packed.shape
+    out = ent[0] if ent is not None else torch.empty((planes, T, C, R) if transpose else (planes, T, R, C),
+                                                     dtype=torch.int16, device=packed.device)
+    check(lib.s2i_split_packed_weight(ptr(packed), T, R, C, planes, 1 if transpose else 0, ptr(out), stream()),
+          "s2i_split_packed_weight")
+    cache[(planes, transpose)] = (out, gen)
     return out
 
 
@@ -176,6 +203,16 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
         part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
     wsb = lib.s2i_conv_workspace_bytes(ctypes.byref(d))
     ws = _ws.get(wsb, x.device)
+    if (MATH_PLANES and w_offset == 0 and packed.dim() == 3 and getattr(packed, '_s2i_gen', None) is not None
+            and lib.s2i_conv_split_eligible(ctypes.byref(d))):
+        transpose = wmode == 0
+        np_, kp = (packed.shape[2], packed.shape[1]) if transpose else (packed.shape[1], packed.shape[2])
+        if kp % 8 == 0:
+            wsp = split_weight(packed, MATH_PLANES, transpose)
+            check(lib.s2i_conv_forward_split(ctypes.byref(d), ptr(x), ptr(cvec), ptr(wsp), MATH_PLANES, np_, kp, ptr(bias),
+                                             ptr(cls_bias), ptr(y), ptr(part), ptr(ws), ws.numel() * 4, stream()),
+                  "s2i_conv_forward_split")
+            return y, part, nparts
     wp = ptr(packed) + 4 * int(w_offset)
     check(lib.s2i_conv_forward_cls(ctypes.byref(d), ptr(x), ptr(cvec), wp, ptr(bias), ptr(cls_bias), ptr(y), ptr(part),
                                    ptr(ws), ws.numel() * 4, stream()), "s2i_conv_forward")
@@ -197,6 +234,14 @@ def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumul
     if out is None:
         full = grad_shape if not I_total else (O, I_total, KH, KW)
         out = torch.empty(full, dtype=torch.float32, device=a.device)
+    if MATH_PLANES:
+        wsb = lib.s2i_wgrad_workspace_bytes_split(ctypes.byref(d), MATH_PLANES)
+        if wsb == 0:
+            check(1, "s2i_wgrad_workspace_bytes_split")
+        ws = _ws.get(wsb, a.device)
+        check(lib.s2i_conv_wgrad_split(ctypes.byref(d), MATH_PLANES, ptr(a), ptr(cvec), ptr(g), ptr(out), ptr(ws),
+                                       ws.numel() * 4, stream()), "s2i_conv_wgrad_split")
+        return out
     wsb = lib.s2i_wgrad_workspace_bytes(ctypes.byref(d))
     if wsb == 0:
         check(1, "s2i_wgrad_workspace_bytes")
