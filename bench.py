@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2"],
+                    help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
+                         "bf16 planes on the bf16 MFMA (DESIGN.md section 9); f32 runs also report bf16x3 beside the value")
     return ap.parse_args()
 
 
@@ -83,6 +86,15 @@ def dominant_kernel_roofline(dev, B):
             "traffic": 385.0e6 if B == 24 else None,
             "kernel": "igemm_fwd_kernel<128,128,2,2> (v_mfma_f32_32x32x2_f32)",
             "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) NHWC, %.2f GFLOP/launch, %.3f ms" % (B, flops / 1e9, ms)}
+
+
+MATH_NOTE = {
+    "f32": "v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)",
+    "bf16x3": "each fp32 operand split into 3 bf16 planes, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; "
+              "error against fp64 <= that of the native fp32 MFMA path (tools/split_bench.py); opt-in (S2I_MATH_PLANES=3)",
+    "bf16x2": "each fp32 operand split into 2 bf16 planes, 3 cross products, fp32 accumulate; ~2^-16 relative per product "
+              "(TF32-class, does not hold the 1e-3 parity tolerance end to end); opt-in (S2I_MATH_PLANES=2)",
+}
 
 
 def cpu_baseline(B):
@@ -132,8 +144,9 @@ def main():
     if args.roofline_only:
         print(json.dumps({"roofline": dominant_kernel_roofline(dev, args.batch)}))
         return
-    from speech_to_image_translation_without_text_amd import model, trainer as T
+    from speech_to_image_translation_without_text_amd import model, ops, trainer as T
     from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
+    ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2}[args.math]
     cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
     cfg.TRAIN.BATCH_SIZE = args.batch
     B = args.batch
@@ -178,24 +191,29 @@ def main():
         if rank == 0:
             print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
 
-    for i in range(args.warmup):
-        out = one_step()
+    def timed(warmup, steps):
+        out = None
+        for i in range(warmup):
+            out = one_step()
+            torch.cuda.synchronize()
+            note("warm-up step %d done" % i)
+        if distributed:
+            torch.distributed.barrier()
         torch.cuda.synchronize()
-        note("warm-up step %d done" % i)
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_step()
-    if distributed:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = one_step()
+        if distributed:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    elapsed, out = timed(args.warmup, args.steps)
     losses = [float(v) for v in out]
     if not all(abs(v) < 1e6 for v in losses):
         raise RuntimeError("non-finite losses after the timed region: %s" % losses)
@@ -209,11 +227,11 @@ def main():
             "metric": "StackGAN-v2 3-stage G+D train-step images/sec at 256px",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.math == "f32" else "f32 as " + args.math, "data": "synthetic",
             "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, fp32, "
                                    "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise" % B,
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "speech_encoder_in_step": bool(args.with_encoder)},
+                       "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math]},
             "step_roofline": {
                 "flops_frac": round(step_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
                 "achieved_tflops": round(step_flops / (ms * 1e-3) / 1e12, 2),
@@ -224,6 +242,17 @@ def main():
         }
         if world == 1:
             line["roofline"] = dominant_kernel_roofline(dev, B)
+            if args.math == "f32":
+                # reported beside the value, never as the value: the same step with the split-bf16 matrix products
+                try:
+                    ops.MATH_PLANES = 3
+                    el3, out3 = timed(3, args.steps)
+                    line["bf16x3_split"] = {"value": round(B * args.steps / el3, 2), "unit": "images/sec",
+                                            "ms_per_step": round(el3 / args.steps * 1e3, 3), "note": MATH_NOTE["bf16x3"]}
+                except Exception as e:  # noqa: BLE001 - the headline number must not depend on this extra leg
+                    line["bf16x3_split"] = {"error": str(e)[:200]}
+                finally:
+                    ops.MATH_PLANES = 0
             if not args.no_cpu_baseline:
                 note("timing the CPU oracle (bounded sample, batch %d)" % args.cpu_baseline_batch)
                 line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)

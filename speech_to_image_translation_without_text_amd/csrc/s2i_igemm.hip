@@ -567,8 +567,9 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_split_kernel(IgemmP p) {
 #pragma unroll
     for (int q = 0; q < BLOADS; ++q)
       if (blds[q] >= 0) *reinterpret_cast<u32x4*>(Bs + blds[q]) = rb[q];
-    __syncthreads();
+    // the MFMA phase of a split chunk is short (0.7 us): put the next chunk's loads in flight before the barrier wait
     if (kc + 1 < c_end) fetch(kc + 1);
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int so = fsw ^ (ks << 5);
@@ -1088,8 +1089,8 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
       for (int pl = 0; pl < NP; ++pl)
         *reinterpret_cast<u32x2*>(Bs + pl * BPLANE + row * BROWB + 16 * (((bcol4 >> 1) ^ sw) & BMASK) + 8 * (bcol4 & 1)) = sp[pl];
     }
-    __syncthreads();
     if (pc + 1 < c_end) fetch(pc + 1);
+    __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 a[NP][TM];

@@ -98,8 +98,18 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 3], ids=["f32", "bf16x3"])
+def math_planes(request):
+    """Native fp32 MFMA products, and the opt-in split-bf16 mode (3 planes: fp32-grade accuracy, same tolerances)."""
+    from speech_to_image_translation_without_text_amd import ops
+    old = ops.MATH_PLANES
+    ops.MATH_PLANES = request.param
+    yield request.param
+    ops.MATH_PLANES = old
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(str(v) for v in c))
-def test_conv_bn_act_fwd_bwd(gpu, case):
+def test_conv_bn_act_fwd_bwd(gpu, case, math_planes):
     from speech_to_image_translation_without_text_amd import ops
     kind, B, H, Cx, Cc, Cout, act, use_res = case
     import zlib
@@ -318,3 +328,49 @@ def test_layout_and_optimizer(gpu):
     avg = p0.to(gpu).clone()
     ops.ema_update(avg, p, 0.999)
     close(avg, 0.999 * p0 + 0.001 * p.cpu(), what="ema", rtol=1e-6, atol=1e-6)
+
+
+def test_split_bf16_products_against_fp64(gpu):
+    """The opt-in split-bf16 matrix products (include/s2i_hip.h): a 4096 x 2048 x 1024 GEMM and a D-tower conv with its
+    input- and weight-gradient against fp64.  Three planes must be at least as accurate as the native fp32 MFMA path
+    (within 1.5x of its error); two planes are TF32-class (mean error below 2e-5 of mean |y|)."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K1, CONV_K4S2, TCONV_K4S2
+    g = torch.Generator(device=gpu).manual_seed(3)
+    old = ops.MATH_PLANES
+    try:
+        # GEMM
+        x = torch.randn(4, 32, 32, 2048, device=gpu, generator=g)
+        w = torch.randn(1024, 2048, device=gpu, generator=g) / 2048 ** 0.5
+        packed = ops.pack_weight(w, ops.PACK_PLAIN)
+        ref = (x.view(-1, 2048).double() @ w.double().t())
+        errs = {}
+        for planes in (0, 2, 3):
+            ops.MATH_PLANES = planes
+            y = ops.conv_raw(CONV_K1, x, None, packed, 1024, wR=packed.shape[1], ldw=packed.shape[2])[0]
+            errs[planes] = float((y.view(-1, 1024).double() - ref).abs().mean() / ref.abs().mean())
+        assert errs[3] <= 1.5 * errs[0], errs
+        assert errs[2] <= 2e-5, errs
+        # conv forward / input gradient / weight gradient of Conv2d(64,128,k4,s2,p1) on (8,64,64,64)
+        xc = torch.randn(8, 64, 64, 64, device=gpu, generator=g)
+        wc = torch.randn(128, 64, 4, 4, device=gpu, generator=g) / 32.0
+        gy = torch.randn(8, 32, 32, 128, device=gpu, generator=g)
+        pk = ops.pack_weight(wc, ops.PACK_PLAIN)
+        xn, wn, gn = (t.double().cpu() for t in (xc.permute(0, 3, 1, 2), wc, gy.permute(0, 3, 1, 2)))
+        xn.requires_grad_(True)
+        wn.requires_grad_(True)
+        yref = torch.nn.functional.conv2d(xn, wn, stride=2, padding=1)
+        yref.backward(gn)
+        refs = (yref.detach(), xn.grad, wn.grad)
+        cerr = {}
+        for planes in (0, 3):
+            ops.MATH_PLANES = planes
+            y = ops.conv_raw(CONV_K4S2, xc, None, pk, 128, wR=pk.shape[1], ldw=pk.shape[2])[0]
+            dx = ops.conv_raw(TCONV_K4S2, gy, None, pk, 64, wmode=1, wR=pk.shape[1], ldw=pk.shape[2])[0]
+            dw = ops.wgrad_raw(CONV_K4S2, xc, None, gy, tuple(wc.shape))
+            outs = (y.permute(0, 3, 1, 2), dx.permute(0, 3, 1, 2), dw)
+            cerr[planes] = [float((o.double().cpu() - r).abs().mean() / r.abs().mean()) for o, r in zip(outs, refs)]
+        for e3, e0 in zip(cerr[3], cerr[0]):
+            assert e3 <= 1.5 * e0 + 1e-9, cerr
+    finally:
+        ops.MATH_PLANES = old

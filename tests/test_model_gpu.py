@@ -48,8 +48,17 @@ def test_forward_full_width_three_stages(gpu):
         assert_close(sample(feat.cpu()), gold['d%d_feat_sample' % i], what="feat%d" % i)
 
 
+@pytest.fixture(params=[0, 3], ids=["f32", "bf16x3"])
+def math_planes(request):
+    from speech_to_image_translation_without_text_amd import ops
+    old = ops.MATH_PLANES
+    ops.MATH_PLANES = request.param
+    yield request.param
+    ops.MATH_PLANES = old
+
+
 @pytest.mark.parametrize("name", ["small3", "full1"])
-def test_train_step_against_reference_and_oracle(gpu, name):
+def test_train_step_against_reference_and_oracle(gpu, name, math_planes):
     from oracle import stackgan_oracle as orc
     from speech_to_image_translation_without_text_amd import trainer as T
     case, gold = CASES[name], load_golden(name)
@@ -349,7 +358,7 @@ def test_evaluate_writes_reference_named_pngs(gpu, tmp_path):
     cfg.TRAIN.FLAG = True
 
 
-def test_full_size_config2_step_against_oracle(gpu):
+def test_full_size_config2_step_against_oracle(gpu, math_planes):
     """BASELINE config 2 at its FULL size (branch_num=3, 64/128/256 px, full width, batch 24, stacked D passes,
     folded c_code): one complete iteration against the CPU oracle on the same seeded inputs."""
     from oracle import stackgan_oracle as orc
