@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2"],
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
                          "bf16 planes on the bf16 MFMA (DESIGN.md section 9); f32 runs also report bf16x3 beside the value")
     return ap.parse_args()
@@ -92,6 +92,9 @@ MATH_NOTE = {
     "f32": "v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)",
     "bf16x3": "each fp32 operand split into 3 bf16 planes, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; "
               "error against fp64 <= that of the native fp32 MFMA path (tools/split_bench.py); opt-in (S2I_MATH_PLANES=3)",
+    "bf16": "operands of the conv GEMMs rounded to bf16 (one plane) on v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations, "
+            "BatchNorm statistics, master weights and Adam stay fp32 (the matrix-product half of BASELINE config 4; "
+            "activations are NOT stored in bf16); opt-in (S2I_MATH_PLANES=1)",
     "bf16x2": "each fp32 operand split into 2 bf16 planes, 3 cross products, fp32 accumulate; ~2^-16 relative per product "
               "(TF32-class, does not hold the 1e-3 parity tolerance end to end); opt-in (S2I_MATH_PLANES=2)",
 }
@@ -146,7 +149,7 @@ def main():
         return
     from speech_to_image_translation_without_text_amd import model, ops, trainer as T
     from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
-    ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2}[args.math]
+    ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}[args.math]
     cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
     cfg.TRAIN.BATCH_SIZE = args.batch
     B = args.batch
@@ -227,9 +230,11 @@ def main():
             "metric": "StackGAN-v2 3-stage G+D train-step images/sec at 256px",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.math == "f32" else "f32 as " + args.math, "data": "synthetic",
-            "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, fp32, "
-                                   "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise" % B,
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16 products / f32"}.get(args.math, "f32 as " + args.math), "data": "synthetic",
+            "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, %s, "
+                                   "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise"
+                                   % (B, "fp32" if args.math != "bf16" else "bf16 matrix products with fp32 accumulate, "
+                                                                            "fp32 activations / master weights / Adam"),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math]},
             "step_roofline": {

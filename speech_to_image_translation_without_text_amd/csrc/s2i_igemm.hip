@@ -1655,7 +1655,7 @@ extern "C" int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, co
                                       const unsigned short* wsplit, int planes, int np, int kp, const float* bias,
                                       const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes,
                                       void* stream) {
-  S2I_REQUIRE(wsplit != nullptr && (planes == 2 || planes == 3), "conv(split): need 2 or 3 bf16 planes");
+  S2I_REQUIRE(wsplit != nullptr && planes >= 1 && planes <= 3, "conv(split): need 1 to 3 bf16 planes");
   S2I_REQUIRE(np > 0 && kp > 0 && (kp % 8) == 0, "conv(split): weight rows must be multiples of 8 bf16 (kp=%d)", kp);
   S2I_REQUIRE(s2i_conv_split_eligible(d), "conv(split): layer not eligible (gathered channels must be multiples of 32)");
   return conv_forward_impl(d, x, cvec, nullptr, wsplit, planes, np, kp, bias, cls_bias, y, part, ws, ws_bytes, stream);
@@ -1663,7 +1663,7 @@ extern "C" int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, co
 
 extern "C" int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, int transpose,
                                        unsigned short* out, void* stream) {
-  S2I_REQUIRE(packed && out && T > 0 && R > 0 && C > 0 && (planes == 2 || planes == 3), "split_packed_weight: bad args");
+  S2I_REQUIRE(packed && out && T > 0 && R > 0 && C > 0 && planes >= 1 && planes <= 3, "split_packed_weight: bad args");
   dim3 grid(s2i_cdiv(C, 32), s2i_cdiv(R, 32), T);
   hipLaunchKernelGGL(split_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, packed, out, R, C, planes, transpose,
                      (long long)T * R * C);
@@ -1673,7 +1673,8 @@ extern "C" int s2i_split_packed_weight(const float* packed, int T, int R, int C,
 
 template <int BM, int BN, int WM, int WN>
 static void launch_split(const IgemmP& p, dim3 grid, int planes, hipStream_t st) {
-  if (planes == 2) hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
+  if (planes == 1) hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, p);
+  else if (planes == 2) hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, p);
 }
 
@@ -1786,13 +1787,14 @@ extern "C" size_t s2i_wgrad_workspace_bytes_split(const s2i_wgrad_desc* d, int p
 
 extern "C" int s2i_conv_wgrad_split(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec,
                                     const float* g, float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
-  S2I_REQUIRE(planes == 2 || planes == 3, "wgrad(split): need 2 or 3 bf16 planes");
+  S2I_REQUIRE(planes >= 1 && planes <= 3, "wgrad(split): need 1 to 3 bf16 planes");
   return conv_wgrad_impl(d, planes, a, cvec, g, grad_oihw, ws, ws_bytes, stream);
 }
 
 template <int BM, int BN, int WM, int WN>
 static void launch_wgrad_split(const WgradP& p, dim3 grid, int planes, hipStream_t st) {
-  if (planes == 2) hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
+  if (planes == 1) hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, st, p);
+  else if (planes == 2) hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_wgrad_split_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, p);
 }
 

@@ -527,3 +527,35 @@ def test_full_size_conv_properties(gpu):
         c = float((x.double() * dx.double()).sum())
         ref = float((y.double().abs() * gy.double().abs()).sum())  # scale of the cancellation
         assert abs(a - b_) <= 1e-6 * ref and abs(a - c) <= 1e-6 * ref, (a, b_, c, ref)
+
+
+def test_bf16_product_mode_tracks_fp32(gpu):
+    """BASELINE config 4's matrix-product half (opt-in S2I_MATH_PLANES=1: conv GEMM operands rounded to bf16, fp32
+    accumulate; activations, BatchNorm statistics, master weights and Adam stay fp32).  No fp32 tolerance applies
+    (SURVEY.md section 8d): the test reports the deviation from the fp32 path and bounds it loosely."""
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
+    case = CASES['small3']
+    batch = make_batch(case)
+    res = {}
+    old = ops.MATH_PLANES
+    try:
+        for planes in (0, 1):
+            ops.MATH_PLANES = planes
+            netG, netsD = build_nets(case)
+            netG.to(gpu)
+            for d in netsD:
+                d.to(gpu)
+            tr = T.condGANTrainer(None, None, 256, False)
+            tr.build(netG, netsD)
+            b = to_dev(batch, gpu)
+            out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'],
+                                b['noise'], b['eps'])
+            torch.cuda.synchronize()
+            res[planes] = ([float(o) for o in out], [f.detach().clone() for f in tr.fake_imgs])
+    finally:
+        ops.MATH_PLANES = old
+    for a, c in zip(res[0][0], res[1][0]):
+        assert abs(a - c) <= 0.03 * abs(a) + 1e-3, res
+    for a, c in zip(res[0][1], res[1][1]):
+        rel = float((a - c).norm() / a.norm())
+        assert rel < 0.03, rel
