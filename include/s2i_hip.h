@@ -282,6 +282,12 @@ int s2i_maxpool_w3s2(const float* x, int B, int H, int W, int C, float* y, void*
  */
 int s2i_lstm_cell(const float* xproj, int ldx, const float* hproj, const int* lens, int B, int T, int Hd,
                   int step, int reverse, float* h, float* c, float* out, int ldo, void* stream);
+/* The same step for all D directions in one launch, with the recurrent projection fused in: gates = xproj[b][t] +
+ * h_in[d][b] . whh_d^T (whh_* are the reference's weight_hh_l0 / weight_hh_l0_reverse, (4*Hd, Hd) row-major);
+ * h_in / h_out [D][B][Hd] are distinct buffers (ping-pong), c [D][B][Hd] in place; direction 1 runs reversed. */
+int s2i_lstm_step(const float* xproj, int ldx, const float* whh_fwd, const float* whh_rev, const int* lens,
+                  int B, int T, int Hd, int D, int step, const float* h_in, float* h_out, float* c, float* out,
+                  int ldo, void* stream);
 /* y[b][c] = mean over the T rows of x[b][t][c] (sent_emb = output.mean(-2), speech_encoder.py:93) */
 int s2i_time_mean(const float* x, int B, int T, int C, float* y, void* stream);
 

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "s2i_cal_loss": (c_int, [P, P, c_int, c_int, P, c_int, P, P]),
     "s2i_maxpool_w3s2": (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
     "s2i_lstm_cell": (c_int, [P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P]),
+    "s2i_lstm_step": (c_int, [P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_int, P]),
     "s2i_time_mean": (c_int, [P, c_int, c_int, c_int, P, P]),
     "s2i_adam_step": (c_int, [P, P, P, P, c_ll, c_float, c_float, c_float, c_float, c_int, P, c_float, P]),
     "s2i_increment": (c_int, [P, P]),

@@ -859,6 +859,66 @@ __global__ void lstm_cell_kernel(const float* __restrict__ xproj, int ldx, const
   h[e] = hn;
   out[((size_t)b * T + t) * ldo + j] = hn;
 }
+// One LSTM time step for every direction in ONE launch: recurrent projection h . W_hh^T fused with the cell update
+// (the two kernels above need 3 launches per step and direction).  Block = 8 hidden units x 32 batch slots; h of the
+// previous step sits in LDS (rows padded by 4 floats), W_hh is read in its original (4H, H) row-major layout with
+// float4 loads along k -- the 8 unit lanes of a wave read 8 rows, the batch lanes share them.
+__global__ __launch_bounds__(256) void lstm_step_kernel(const float* __restrict__ xproj, int ldx,
+                                                        const float* __restrict__ whh0, const float* __restrict__ whh1,
+                                                        const int* __restrict__ lens, int B, int T, int Hd, int step,
+                                                        const float* __restrict__ h_in, float* __restrict__ h_out,
+                                                        float* __restrict__ c, float* __restrict__ out, int ldo) {
+  extern __shared__ __attribute__((aligned(16))) float hs[];  // h: [32][Hd + 4], then W slice: [4 gates x 8 units][Hd + 4]
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int ul = tid & 7, u = blockIdx.x * 8 + ul, b = tid >> 3;
+  const int LDH = Hd + 4, Q = Hd / 4;
+  float* wsm = hs + 32 * LDH;
+  const float* hin = h_in + (size_t)d * B * Hd;
+  const float* w = d ? whh1 : whh0;
+  // both tiles with coalesced, independent float4 loads (one memory latency for the whole step)
+  for (int e = tid; e < 32 * Q; e += 256) {
+    const int r = e / Q, q = e - r * Q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < B) v = *reinterpret_cast<const f32x4*>(hin + (size_t)r * Hd + q * 4);
+    *reinterpret_cast<f32x4*>(hs + r * LDH + q * 4) = v;
+    const int grow = (r >> 3) * Hd + blockIdx.x * 8 + (r & 7);  // row r = gate * 8 + unit
+    *reinterpret_cast<f32x4*>(wsm + r * LDH + q * 4) = *reinterpret_cast<const f32x4*>(w + (size_t)grow * Hd + q * 4);
+  }
+  __syncthreads();
+  const float* w0 = wsm + (0 * 8 + ul) * LDH;
+  const float* w1 = wsm + (1 * 8 + ul) * LDH;
+  const float* w2 = wsm + (2 * 8 + ul) * LDH;
+  const float* w3 = wsm + (3 * 8 + ul) * LDH;
+  const float* hp = hs + b * LDH;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+#pragma unroll 4
+  for (int k = 0; k < Hd; k += 4) {
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(hp + k);
+    a0 += hv * *reinterpret_cast<const f32x4*>(w0 + k);
+    a1 += hv * *reinterpret_cast<const f32x4*>(w1 + k);
+    a2 += hv * *reinterpret_cast<const f32x4*>(w2 + k);
+    a3 += hv * *reinterpret_cast<const f32x4*>(w3 + k);
+  }
+  if (b >= B) return;
+  const size_t e = ((size_t)d * B + b) * Hd + u;
+  const int len = lens[b];
+  if (step >= len) {  // finished sequence: the state is carried unchanged (packed-sequence rule)
+    h_out[e] = h_in[e];
+    return;
+  }
+  const int t = d ? len - 1 - step : step;
+  const float* xp = xproj + ((size_t)b * T + t) * ldx + (size_t)d * 4 * Hd;
+  const float gi = sigmoidf_(xp[u] + (a0[0] + a0[1] + a0[2] + a0[3]));
+  const float gf = sigmoidf_(xp[Hd + u] + (a1[0] + a1[1] + a1[2] + a1[3]));
+  const float gg = tanhf(xp[2 * Hd + u] + (a2[0] + a2[1] + a2[2] + a2[3]));
+  const float go = sigmoidf_(xp[3 * Hd + u] + (a3[0] + a3[1] + a3[2] + a3[3]));
+  const float cn = gf * c[e] + gi * gg;
+  const float hn = go * tanhf(cn);
+  c[e] = cn;
+  h_out[e] = hn;
+  out[((size_t)b * T + t) * ldo + (size_t)d * Hd + u] = hn;
+}
 __global__ void time_mean_kernel(const float* __restrict__ x, int B, int T, int C, float* __restrict__ y) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= B * C) return;
@@ -1283,6 +1343,26 @@ extern "C" int s2i_lstm_cell(const float* xproj, int ldx, const float* hproj, co
   hipLaunchKernelGGL(lstm_cell_kernel, dim3((B * Hd + 255) / 256), dim3(256), 0, ST, xproj, ldx, hproj, lens, B, T, Hd,
                      step, reverse, h, c, out, ldo);
   S2I_LAUNCH_CHECK("lstm_cell");
+  return 0;
+}
+extern "C" int s2i_lstm_step(const float* xproj, int ldx, const float* whh_fwd, const float* whh_rev, const int* lens,
+                             int B, int T, int Hd, int D, int step, const float* h_in, float* h_out, float* c, float* out,
+                             int ldo, void* stream) {
+  S2I_REQUIRE(xproj && whh_fwd && lens && h_in && h_out && c && out && h_in != h_out, "lstm_step: bad pointers");
+  S2I_REQUIRE((D == 1 || (D == 2 && whh_rev)) && B > 0 && B <= 32 && T > 0 && step >= 0 && Hd > 0 && (Hd % 8) == 0 &&
+                  Hd <= 512, "lstm_step: unsupported extents (B=%d Hd=%d D=%d)", B, Hd, D);
+  S2I_REQUIRE(ldx >= D * 4 * Hd && ldo >= D * Hd, "lstm_step: row strides too small");
+  const size_t shb = (size_t)2 * 32 * (Hd + 4) * sizeof(float);
+  S2I_REQUIRE(shb <= 160 * 1024, "lstm_step: Hd=%d needs %zu bytes of LDS", Hd, shb);
+  static bool attr_set = false;
+  if (shb > 65536 && !attr_set) {
+    S2I_REQUIRE(hipFuncSetAttribute((const void*)lstm_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) ==
+                    hipSuccess, "lstm_step: cannot raise the dynamic LDS limit");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lstm_step_kernel, dim3(Hd / 8, D), dim3(256), shb, ST, xproj, ldx, whh_fwd, whh_rev, lens, B, T, Hd,
+                     step, h_in, h_out, c, out, ldo);
+  S2I_LAUNCH_CHECK("lstm_step");
   return 0;
 }
 extern "C" int s2i_time_mean(const float* x, int B, int T, int C, float* y, void* stream) {

@@ -107,7 +107,9 @@ class CNNRNN(nn.Module):
         w_ih = torch.cat([getattr(rnn, "weight_ih_l0" + s_) for s_ in sfx], 0).contiguous()       # (D*4H, E)
         b_ih = torch.cat([getattr(rnn, "bias_ih_l0" + s_) + getattr(rnn, "bias_hh_l0" + s_) for s_ in sfx], 0)
         w_hh = [ops.pack_weight(getattr(rnn, "weight_hh_l0" + s_).contiguous(), PACK_PLAIN) for s_ in sfx]
-        prep = dict(layers=layers, w_ih=ops.pack_weight(w_ih, PACK_PLAIN), b_ih=b_ih.contiguous(), w_hh=w_hh)
+        w_hh_raw = [getattr(rnn, "weight_hh_l0" + s_).detach().contiguous() for s_ in sfx]
+        prep = dict(layers=layers, w_ih=ops.pack_weight(w_ih, PACK_PLAIN), b_ih=b_ih.contiguous(), w_hh=w_hh,
+                    w_hh_raw=w_hh_raw)
         self._prepared = (sig, prep)
         return prep
 
@@ -151,14 +153,25 @@ class CNNRNN(nn.Module):
         xproj, _, _ = ops.conv_raw(CONV_K1, h.view(B, 1, L, E), None, w_ih, D * 4 * Hd, wR=w_ih.shape[1], ldw=w_ih.shape[2],
                                    bias=prep["b_ih"])                   # [B, 1, L, D*4H]
         out = torch.zeros((B, L, D * Hd), dtype=torch.float32, device=h.device)
-        for d in range(D):
-            hs = torch.zeros((B, 1, 1, Hd), dtype=torch.float32, device=h.device)
-            cs = torch.zeros((B, Hd), dtype=torch.float32, device=h.device)
-            w_hh = prep["w_hh"][d]
+        if B <= 32 and Hd % 8 == 0 and Hd <= 512:
+            # one launch per time step for both directions: recurrent projection + cell fused (s2i_lstm_step)
+            hbuf = torch.zeros((2, D, B, Hd), dtype=torch.float32, device=h.device)
+            cs = torch.zeros((D, B, Hd), dtype=torch.float32, device=h.device)
+            raw = prep["w_hh_raw"]
             for step in range(max(lens_host)):
-                hproj, _, _ = ops.conv_raw(CONV_K1, hs, None, w_hh, 4 * Hd, wR=w_hh.shape[1], ldw=w_hh.shape[2])
-                check(lib.s2i_lstm_cell(ptr(xproj) + 4 * d * 4 * Hd, D * 4 * Hd, ptr(hproj), ptr(lens_dev), B, L, Hd, step,
-                                        d, ptr(hs), ptr(cs), ptr(out) + 4 * d * Hd, D * Hd, stream()), "s2i_lstm_cell")
+                check(lib.s2i_lstm_step(ptr(xproj), D * 4 * Hd, ptr(raw[0]), ptr(raw[-1]), ptr(lens_dev), B, L, Hd, D, step,
+                                        ptr(hbuf[step & 1]), ptr(hbuf[(step + 1) & 1]), ptr(cs), ptr(out), D * Hd, stream()),
+                      "s2i_lstm_step")
+        else:
+            for d in range(D):
+                hs = torch.zeros((B, 1, 1, Hd), dtype=torch.float32, device=h.device)
+                cs = torch.zeros((B, Hd), dtype=torch.float32, device=h.device)
+                w_hh = prep["w_hh"][d]
+                for step in range(max(lens_host)):
+                    hproj, _, _ = ops.conv_raw(CONV_K1, hs, None, w_hh, 4 * Hd, wR=w_hh.shape[1], ldw=w_hh.shape[2])
+                    check(lib.s2i_lstm_cell(ptr(xproj) + 4 * d * 4 * Hd, D * 4 * Hd, ptr(hproj), ptr(lens_dev), B, L, Hd,
+                                            step, d, ptr(hs), ptr(cs), ptr(out) + 4 * d * Hd, D * Hd, stream()),
+                          "s2i_lstm_cell")
         sent = torch.empty((B, D * Hd), dtype=torch.float32, device=h.device)
         check(lib.s2i_time_mean(ptr(out), B, L, D * Hd, ptr(sent), stream()), "s2i_time_mean")
         return out.transpose(1, 2), sent.view(-1, self.nsent * self.num_direction)
