@@ -126,26 +126,7 @@ typedef struct s2i_wgrad_desc {
   int O, I, KH, KW; /* shape of the OIHW gradient tensor written                                */
   int accumulate;   /* 1: grad += result, 0: grad = result                                      */
   int i_off;        /* the I input channels computed here are channels [i_off, i_off+I) of a       */
-  int I_total;      /* ---- split-bf16 matrix products ("bf16x2" / "bf16x3" math modes; opt-in) -------------------------
- * Same convolution as s2i_conv_forward_cls, with every fp32 operand written as a sum of `planes` bf16 numbers and the
- * products taken by v_mfma_f32_32x32x16_bf16 with fp32 accumulation (planes = 2: 3 products, ~2^-16 relative;
- * planes = 3: 6 products, ~2^-23).  wsplit holds the weights pre-split as [plane][tap][np][kp] bf16, n = output column of the
- * GEMM, k = its reduction index (s2i_split_packed_weight: transpose = 1 for the forward, 0 for the input gradient that
- * the fp32 path expresses with wmode = 1).  Eligible when the gathered channel count (and Cc) are multiples of 32. */
-int s2i_conv_split_eligible(const s2i_conv_desc* d);
-int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, const float* cvec,
-                           const unsigned short* wsplit, int planes, int np, int kp, const float* bias,
-                           const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes,
-                           void* stream);
-/* weight gradient with split-bf16 products (both operands are split while they are staged) */
-size_t s2i_wgrad_workspace_bytes_split(const s2i_wgrad_desc* d, int planes);
-int s2i_conv_wgrad_split(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec,
-                         const float* g, float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
-/* packed fp32 weights P[T][R][C] (s2i_pack_conv_weight) -> bf16 planes [plane][T][R][C] or, transposed, [plane][T][C][R] */
-int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, int transpose,
-                            unsigned short* out, void* stream);
-
-/* parameter with I_total input channels (0 = I): the c_code / h_code split    */
+  int I_total;      /* parameter with I_total input channels (0 = I): the c_code / h_code split    */
 } s2i_wgrad_desc;
 
 size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);
@@ -156,6 +137,27 @@ size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);
  */
 int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
                    float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- split-bf16 matrix products (1 / 2 / 3 bf16 planes; opt-in) ---------------------
+ * Same convolution as s2i_conv_forward_cls, with every fp32 operand written as a sum of `planes` bf16 numbers and the
+ * products taken by v_mfma_f32_32x32x16_bf16 with fp32 accumulation (planes = 2: 3 products, ~2^-16 relative;
+ * planes = 3: 6 products, ~2^-23).  wsplit holds the weights pre-split as [plane][tap][np][kp] bf16, n = output column of the
+ * GEMM, k = its reduction index (s2i_split_packed_weight: out_cr for the forward, out_rc for the input gradient that
+ * the fp32 path expresses with wmode = 1).  Eligible when the gathered channel count (and Cc) are multiples of 32. */
+int s2i_conv_split_eligible(const s2i_conv_desc* d);
+int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, const float* cvec,
+                           const unsigned short* wsplit, int planes, int np, int kp, const float* bias,
+                           const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes,
+                           void* stream);
+/* weight gradient with split-bf16 products (both operands are split while they are staged) */
+size_t s2i_wgrad_workspace_bytes_split(const s2i_wgrad_desc* d, int planes);
+int s2i_conv_wgrad_split(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec,
+                         const float* g, float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+/* packed fp32 weights P[T][R][C] (s2i_pack_conv_weight) -> bf16 planes, both operand layouts from one read:
+   out_rc [plane][T][R][C] (input gradient) and out_cr [plane][T][C][R] (forward); either may be NULL */
+int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, unsigned short* out_rc,
+                            unsigned short* out_cr, void* stream);
+
 
 /* OIHW parameter -> packed P[t][Ip][Op] (Ip >= I, Op = O rounded up to 4; padding zero filled) */
 int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int KH, int KW,

@@ -42,7 +42,7 @@ _SIGNATURES = {
     "s2i_conv_forward_cls": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
     "s2i_conv_split_eligible": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_forward_split": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
-    "s2i_split_packed_weight": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P]),
+    "s2i_split_packed_weight": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "s2i_wgrad_workspace_bytes_split": (c_size_t, [ctypes.POINTER(WgradDesc), c_int]),
     "s2i_conv_wgrad_split": (c_int, [ctypes.POINTER(WgradDesc), c_int, P, P, P, P, P, c_size_t, P]),
     "s2i_cvec_bias_table": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),

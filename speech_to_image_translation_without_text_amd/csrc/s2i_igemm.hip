@@ -691,9 +691,11 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_split_kernel(IgemmP p) {
   }
 }
 
-// fp32 packed weights P[T][R][C] -> NP bf16 planes, [plane][T][R][C] (transpose = 0) or [plane][T][C][R] (transpose = 1)
-__global__ __launch_bounds__(256) void split_packed_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                           int R, int C, int NP, int transpose, long long plane) {
+// fp32 packed weights P[T][R][C] -> NP bf16 planes in BOTH operand layouts from one read:
+//   dst_rc [plane][T][R][C] (input gradient: n = r, k = c) and dst_cr [plane][T][C][R] (forward: n = c, k = r); either may be null
+__global__ __launch_bounds__(256) void split_packed_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst_rc,
+                                                           unsigned short* __restrict__ dst_cr, int R, int C, int NP,
+                                                           long long plane) {
   __shared__ float tile[32][33];
   const int t = blockIdx.z;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
@@ -707,15 +709,29 @@ __global__ __launch_bounds__(256) void split_packed_kernel(const float* __restri
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    int orow, ocol;
-    float v;
-    if (transpose) { orow = c0 + ty + 8 * k; ocol = r0 + tx; v = tile[tx][ty + 8 * k]; if (orow >= C || ocol >= R) continue; }
-    else { orow = r0 + ty + 8 * k; ocol = c0 + tx; v = tile[ty + 8 * k][tx]; if (orow >= R || ocol >= C) continue; }
-    const size_t o = transpose ? ((size_t)t * C + orow) * R + ocol : ((size_t)t * R + orow) * C + ocol;
-    for (int pl = 0; pl < NP; ++pl) {
-      const __bf16 h = (__bf16)v;
-      dst[pl * plane + o] = __builtin_bit_cast(unsigned short, h);
-      v -= (float)h;
+    if (dst_rc) {
+      const int r = r0 + ty + 8 * k, c = c0 + tx;
+      if (r < R && c < C) {
+        float v = tile[ty + 8 * k][tx];
+        const size_t o = ((size_t)t * R + r) * C + c;
+        for (int pl = 0; pl < NP; ++pl) {
+          const __bf16 h = (__bf16)v;
+          dst_rc[pl * plane + o] = __builtin_bit_cast(unsigned short, h);
+          v -= (float)h;
+        }
+      }
+    }
+    if (dst_cr) {
+      const int c = c0 + ty + 8 * k, r = r0 + tx;
+      if (r < R && c < C) {
+        float v = tile[tx][ty + 8 * k];
+        const size_t o = ((size_t)t * C + c) * R + r;
+        for (int pl = 0; pl < NP; ++pl) {
+          const __bf16 h = (__bf16)v;
+          dst_cr[pl * plane + o] = __builtin_bit_cast(unsigned short, h);
+          v -= (float)h;
+        }
+      }
     }
   }
 }
@@ -1661,11 +1677,12 @@ extern "C" int s2i_conv_forward_split(const s2i_conv_desc* d, const float* x, co
   return conv_forward_impl(d, x, cvec, nullptr, wsplit, planes, np, kp, bias, cls_bias, y, part, ws, ws_bytes, stream);
 }
 
-extern "C" int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, int transpose,
-                                       unsigned short* out, void* stream) {
-  S2I_REQUIRE(packed && out && T > 0 && R > 0 && C > 0 && planes >= 1 && planes <= 3, "split_packed_weight: bad args");
+extern "C" int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, unsigned short* out_rc,
+                                       unsigned short* out_cr, void* stream) {
+  S2I_REQUIRE(packed && (out_rc || out_cr) && T > 0 && R > 0 && C > 0 && planes >= 1 && planes <= 3,
+              "split_packed_weight: bad args");
   dim3 grid(s2i_cdiv(C, 32), s2i_cdiv(R, 32), T);
-  hipLaunchKernelGGL(split_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, packed, out, R, C, planes, transpose,
+  hipLaunchKernelGGL(split_packed_kernel, grid, dim3(256), 0, (hipStream_t)stream, packed, out_rc, out_cr, R, C, planes,
                      (long long)T * R * C);
   S2I_LAUNCH_CHECK("split_packed_weight");
   return 0;

@@ -152,23 +152,20 @@ MATH_PLANES = int(os.environ.get("S2I_MATH_PLANES", "0"))
 
 
 def split_weight(packed, planes, transpose):
-    """bf16 planes of a packed weight tensor P[T][R][C], cached on the tensor object until it is re-packed."""
+    """bf16 planes of a packed weight tensor P[T][R][C], cached on the tensor object until it is re-packed.  Both operand
+    layouts ([plane][T][R][C] for the input gradient, [plane][T][C][R] for the forward) come from one launch."""
     lib = _lib_ready()
     cache = getattr(packed, '_s2i_split', None)
-    if cache is None:
-        cache = {}
-        packed._s2i_split = cache
     gen = packed._s2i_gen
-    ent = cache.get((planes, transpose))
-    if ent is not None and ent[1] == gen:
-        return ent[0]
-    T, R, C = packed.shape
-    out = ent[0] if ent is not None else torch.empty((planes, T, C, R) if transpose else (planes, T, R, C),
-                                                     dtype=torch.int16, device=packed.device)
-    check(lib.s2i_split_packed_weight(ptr(packed), T, R, C, planes, 1 if transpose else 0, ptr(out), stream()),
-          "s2i_split_packed_weight")
-    cache[(planes, transpose)] = (out, gen)
-    return out
+    if cache is None or cache[0] != gen or cache[1] != planes:
+        T, R, C = packed.shape
+        rc, cr = (cache[2], cache[3]) if cache is not None and cache[1] == planes else (
+            torch.empty((planes, T, R, C), dtype=torch.int16, device=packed.device),
+            torch.empty((planes, T, C, R), dtype=torch.int16, device=packed.device))
+        check(lib.s2i_split_packed_weight(ptr(packed), T, R, C, planes, ptr(rc), ptr(cr), stream()), "s2i_split_packed_weight")
+        cache = (gen, planes, rc, cr)
+        packed._s2i_split = cache
+    return cache[3] if transpose else cache[2]
 
 
 # ---- raw kernels ------------------------------------------------------------------------------------

@@ -99,3 +99,18 @@ def test_weights_init_matches_reference_rules():
     assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-5)          # orthogonal rows
     assert float(bn.bias.abs().max()) == 0.0 and abs(float(bn.weight.mean()) - 1.0) < 0.05
     assert float(lin.bias.abs().max()) == 0.0
+
+
+def test_header_is_valid_c(tmp_path):
+    """include/s2i_hip.h is the drop-in boundary: it must compile as plain C (no C++-only constructs, every declaration at
+    file scope)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "h.c"
+    src.write_text('#include "s2i_hip.h"\nint main(void) { s2i_conv_desc c; s2i_wgrad_desc w; (void)c; (void)w; return 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o",
+                    str(tmp_path / "h.o")], check=True)
