@@ -691,30 +691,51 @@ __global__ __launch_bounds__(256) void logit_fwd_kernel(const float* __restrict_
   }
   if (threadIdx.x == 0) prob[b] = sigmoidf_(sh[0] + (bias ? bias[0] : 0.f));
 }
-__global__ void logit_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                 const float* __restrict__ prob, const float* __restrict__ dprob, int B, int C,
-                                 float* __restrict__ dx, int acc_dx, float* __restrict__ dw,
-                                 float* __restrict__ dbias, int acc_dw) {
+__global__ __launch_bounds__(256) void logit_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ prob, const float* __restrict__ dprob,
+                                                        int B, int C, float* __restrict__ dx, int acc_dx,
+                                                        float* __restrict__ dw, float* __restrict__ dbias, int acc_dw) {
+  // dl[b] = d loss / d logit once per block; then every thread owns one (pixel, channel) column of x and walks the
+  // batch eight rows at a time so that eight independent loads are in flight (the serial walk was latency-bound: 39 us)
+  __shared__ float dl_s[256];
   const int n = 16 * C;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) {
-    const int pix = e / C, c = e - pix * C;
-    const float wv = w[c * 16 + pix];
-    float gw = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float pr = prob[b];
-      const float dl = dprob[b] * pr * (1.f - pr);
-      const size_t off = (size_t)b * n + e;
-      gw += dl * x[off];
-      if (dx) dx[off] = acc_dx ? dx[off] + dl * wv : dl * wv;
+  const bool live = e < n;
+  int pix = 0, c = 0;
+  if (live) { pix = e / C; c = e - pix * C; }
+  const float wv = live ? w[c * 16 + pix] : 0.f;
+  float gw = 0.f, gb = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 256) {
+    const int nb = min(256, B - b0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const float pr = prob[b0 + threadIdx.x];
+      dl_s[threadIdx.x] = dprob[b0 + threadIdx.x] * pr * (1.f - pr);
     }
-    if (dw) dw[c * 16 + pix] = acc_dw ? dw[c * 16 + pix] + gw : gw;
+    __syncthreads();
+    if (e == 0 && dbias)
+      for (int b = 0; b < nb; ++b) gb += dl_s[b];
+    if (!live) continue;
+    for (int b1 = 0; b1 < nb; b1 += 8) {
+      float xv[8], dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = b1 + j < nb;
+        const size_t off = (size_t)(b0 + b1 + j) * n + e;
+        xv[j] = ok ? x[off] : 0.f;
+        dv[j] = (ok && dx && acc_dx) ? dx[off] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (b1 + j >= nb) break;
+        const float dl = dl_s[b1 + j];
+        gw += dl * xv[j];
+        if (dx) dx[(size_t)(b0 + b1 + j) * n + e] = dv[j] + dl * wv;
+      }
+    }
   }
-  if (e == 0 && dbias) {
-    float gb = 0.f;
-    for (int b = 0; b < B; ++b) gb += dprob[b] * prob[b] * (1.f - prob[b]);
-    dbias[0] = acc_dw ? dbias[0] + gb : gb;
-  }
+  if (live && dw) dw[c * 16 + pix] = acc_dw ? dw[c * 16 + pix] + gw : gw;
+  if (e == 0 && dbias) dbias[0] = acc_dw ? dbias[0] + gb : gb;
 }
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ prob, float target, int B,
                                                       float weight, float* __restrict__ loss, int accumulate) {
