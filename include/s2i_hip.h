@@ -162,6 +162,16 @@ int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes
 /* OIHW parameter -> packed P[t][Ip][Op] (Ip >= I, Op = O rounded up to 4; padding zero filled) */
 int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int KH, int KW,
                          int Ip, int mode, void* stream);
+/* The same for a whole network in one launch: `items` is a DEVICE array; item k owns the linear blocks
+   [block0, block0 + gx * ceil(Ip / 8)) with gx = ceil(Op / 32), block0 ascending; total_blocks = their sum;
+   max_taps = the largest KH*KW.  Used after the fused Adam step (trainer.py:236-252 equivalent). */
+typedef struct s2i_pack_item {
+  const float* w;   /* OIHW parameter */
+  float* packed;    /* P[t][Ip][Op]   */
+  int O, I, KH, KW, Ip, mode, gx, block0;
+} s2i_pack_item;
+int s2i_pack_conv_weights_batched(const s2i_pack_item* items_dev, int n, int total_blocks, int max_taps,
+                                  void* stream);
 
 /* ---- BatchNorm (training statistics) + activation ------------------------------------------ */
 /*

@@ -31,6 +31,11 @@ class WgradDesc(ctypes.Structure):
                                      "O", "I", "KH", "KW", "accumulate", "i_off", "I_total")]
 
 
+class PackItem(ctypes.Structure):
+    _fields_ = [("w", c_void_p), ("packed", c_void_p)] + [(n, c_int) for n in ("O", "I", "KH", "KW", "Ip", "mode", "gx",
+                                                                               "block0")]
+
+
 P = c_void_p
 _SIGNATURES = {
     "s2i_last_error": (ctypes.c_char_p, []),
@@ -52,6 +57,7 @@ _SIGNATURES = {
     "s2i_wgrad_workspace_bytes": (c_size_t, [ctypes.POINTER(WgradDesc)]),
     "s2i_conv_wgrad": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P, c_size_t, P]),
     "s2i_pack_conv_weight": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "s2i_pack_conv_weights_batched": (c_int, [P, c_int, c_int, c_int, P]),
     "s2i_bn_finalize": (c_int, [P, c_int, c_int, c_int, c_ll, P, P, P, P, P, c_float, c_float, P, P]),
     "s2i_bn_eval_coeffs": (c_int, [c_int, P, P, P, P, c_float, P, P]),
     "s2i_bn_act_forward": (c_int, [P, c_ll, c_int, c_int, P, c_int, P, P, P]),

@@ -1433,11 +1433,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
 }
 
 // OIHW -> packed P[t][Ip][Op] through an LDS tile of 32 cout x 8 cin x taps: coalesced on both sides.
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
-                                                          int O, int I, int Tp, int Ip, int Op, int T, int mode) {
-  extern __shared__ float tile[];  // [32][8*Tp + 1]
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int Tp,
+                                          int Ip, int Op, int T, int mode, int bx, int by, float* tile) {
   const int tid = threadIdx.x;
-  const int o0 = blockIdx.x * 32, i0 = blockIdx.y * 8;
+  const int o0 = bx * 32, i0 = by * 8;
   const int ostride = 8 * Tp + 1;
   const int nload = 32 * 8 * Tp;
   for (int e = tid; e < nload; e += 256) {
@@ -1469,6 +1468,24 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     }
     packed[((size_t)t * Ip + i) * Op + o] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
+                                                          int O, int I, int Tp, int Ip, int Op, int T, int mode) {
+  extern __shared__ float tile[];  // [32][8*Tp + 1]
+  pack_tile(w, packed, O, I, Tp, Ip, Op, T, mode, blockIdx.x, blockIdx.y, tile);
+}
+
+// every conv weight of one network in ONE launch (after the fused Adam step): the table lives in device memory
+__global__ __launch_bounds__(256) void pack_weight_batched_kernel(const s2i_pack_item* __restrict__ items, int n) {
+  extern __shared__ float tile[];
+  int k = 0;
+  while (k + 1 < n && (int)blockIdx.x >= items[k + 1].block0) ++k;  // n is a few dozen; block0 ascending
+  const s2i_pack_item it = items[k];
+  const int local = blockIdx.x - it.block0;
+  const int T = it.mode == S2I_PACK_UPFOLD ? 16 : it.KH * it.KW;
+  pack_tile(it.w, it.packed, it.O, it.I, it.KH * it.KW, it.Ip, (it.O + 3) & ~3, T, it.mode, local % it.gx, local / it.gx,
+            tile);
 }
 
 // ---- host-side planning ------------------------------------------------------------------------
@@ -1888,6 +1905,15 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
                        d->i_off, d->I_total > 0 ? d->I_total : d->I);
   }
   S2I_LAUNCH_CHECK("wgrad_finish");
+  return 0;
+}
+
+extern "C" int s2i_pack_conv_weights_batched(const s2i_pack_item* items_dev, int n, int total_blocks, int max_taps,
+                                             void* stream) {
+  S2I_REQUIRE(items_dev && n > 0 && total_blocks > 0 && max_taps > 0 && max_taps <= 16, "pack(batched): bad args");
+  const size_t shb = (size_t)32 * (8 * max_taps + 1) * sizeof(float);
+  hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(total_blocks), dim3(256), shb, (hipStream_t)stream, items_dev, n);
+  S2I_LAUNCH_CHECK("pack_weight_batched");
   return 0;
 }
 

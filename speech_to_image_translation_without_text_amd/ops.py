@@ -116,16 +116,48 @@ def packed_weight(w, mode=0):
     return packed
 
 
+_pack_tables = {}
+
+
 def refresh_packed(params):
-    """Re-pack every cached layout of these parameters in place."""
+    """Re-pack every cached layout of these parameters in place -- one launch for the whole list (the table of
+    (parameter, packed copy, shape) entries lives on the device and is rebuilt only when a pointer changes)."""
+    entries = []
     for p in params:
         packs = getattr(p, '_s2i_packs', None)
         if packs:
             for mode, ent in list(packs.items()):
                 if ent[0].device == p.device:
-                    packs[mode] = (pack_weight(p, mode, out=ent[0]), p._version, p.data_ptr())
+                    entries.append((p, mode, ent[0]))
                 else:
                     del packs[mode]
+    if not entries:
+        return
+    lib = _lib_ready()
+    key = tuple((p.data_ptr(), mode, out.data_ptr()) for p, mode, out in entries)
+    tab = _pack_tables.get(key)
+    if tab is None:
+        items = (_lib.PackItem * len(entries))()
+        block0, max_taps = 0, 1
+        for k, (p, mode, out) in enumerate(entries):
+            if p.dim() == 2:
+                O, I, KH, KW = p.shape[0], p.shape[1], 1, 1
+            else:
+                O, I, KH, KW = p.shape
+            Ip, Op = _roundup4(I), _roundup4(O)
+            gx = (Op + 31) // 32
+            items[k] = _lib.PackItem(p.data_ptr(), out.data_ptr(), O, I, KH, KW, Ip, mode, gx, block0)
+            block0 += gx * ((Ip + 7) // 8)
+            max_taps = max(max_taps, KH * KW)
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(entries[0][0].device)
+        tab = (key, raw, len(entries), block0, max_taps)
+        if len(_pack_tables) > 64:
+            _pack_tables.clear()
+        _pack_tables[key] = tab
+    check(lib.s2i_pack_conv_weights_batched(ptr(tab[1]), tab[2], tab[3], tab[4], stream()), "s2i_pack_conv_weights_batched")
+    for p, mode, out in entries:
+        out._s2i_gen = getattr(out, '_s2i_gen', 0) + 1
+        p._s2i_packs[mode] = (out, p._version, p.data_ptr())
 
 
 def pack_weight(w, mode, out=None):
