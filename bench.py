@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    ap.add_argument("--no-side-leg", action="store_true", help="skip the extra bf16x3 measurement of f32 runs (profiling)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
                          "bf16 planes on the bf16 MFMA (DESIGN.md section 9); f32 runs also report bf16x3 beside the value")
@@ -247,7 +248,7 @@ def main():
         }
         if world == 1:
             line["roofline"] = dominant_kernel_roofline(dev, B)
-            if args.math == "f32":
+            if args.math == "f32" and not args.no_side_leg:
                 # reported beside the value, never as the value: the same step with the split-bf16 matrix products
                 try:
                     ops.MATH_PLANES = 3
