@@ -239,6 +239,12 @@ class condGANTrainer(object):
         self.d_streams = os.environ.get("S2I_D_STREAMS", "1") == "1" and torch.cuda.is_available()
         self._side_streams = None
 
+    def _make_d_streams(self):
+        """One stream per discriminator; the largest one is the critical path of the step and gets the high priority,
+        so the smaller networks' kernels fill its gaps instead of delaying it (S2I_D_PRIORITY=0: equal priorities)."""
+        prio = os.environ.get("S2I_D_PRIORITY", "1") == "1"
+        return [torch.cuda.Stream(priority=-1 if (prio and i == self.num_Ds - 1) else 0) for i in range(self.num_Ds)]
+
     # -- set-up -------------------------------------------------------------------------------------------
     def build(self, netG=None, netsD=None, start_count=0):
         """Networks + flat optimisers.  `train()` calls this; benches and tests may pass their own nets."""
@@ -355,7 +361,7 @@ class condGANTrainer(object):
             # runs on its own HIP stream (autograd replays every backward on its forward stream)
             main = torch.cuda.current_stream() if self.d_streams else None
             if self.d_streams and self._side_streams is None:
-                self._side_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
+                self._side_streams = self._make_d_streams()
             for i in range(self.num_Ds):
                 if self.d_streams:
                     self._side_streams[i].wait_stream(main)  # fake images / mu; D_i's own update is already in order
@@ -414,7 +420,7 @@ class condGANTrainer(object):
             # can start as soon as D_i is updated, while a larger discriminator is still in its own update.
             main = torch.cuda.current_stream()
             if self._side_streams is None:
-                self._side_streams = [torch.cuda.Stream() for _ in range(self.num_Ds)]
+                self._side_streams = self._make_d_streams()
             errs = []
             for i in reversed(range(self.num_Ds)):  # largest first: it is the critical path
                 st = self._side_streams[i]
