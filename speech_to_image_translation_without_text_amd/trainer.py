@@ -406,8 +406,7 @@ class condGANTrainer(object):
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
         ops.DIRECT_PARAM_GRAD = True  # kernels accumulate into the flat gradient buffers (zeroed per update)
-        # opt-in (S2I_WGRAD_STREAM=1): -0.5 ms/step on one GPU, but the record_stream bookkeeping it needs made a
-        # two-process rehearsal on one shared GPU 6x slower, and it cannot be validated on a multi-GPU node here
+        # opt-in (S2I_WGRAD_STREAM=1): a rejected experiment, slower than the default
         ops.WGRAD_SIDE_STREAM = self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"
         self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
