@@ -1,0 +1,66 @@
+"""Two data-parallel ranks on ONE GPU (gloo collectives, both ranks on cuda:0): the full train step of SURVEY.md §8e --
+rank-0 broadcast, per-network gradient all-reduce issued from the discriminator streams, 1/world folded into the fused
+Adam -- must keep the replicas bit-identical while they see different data.  (RCCL itself cannot be exercised on a
+one-GPU box; the control flow is the same.)"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import CASES, build_nets, make_batch
+    from speech_to_image_translation_without_text_amd import trainer as T
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        case = dict(CASES["small3"], seed=100 + rank, data_seed=7 + rank)  # different weights AND data per rank
+        netG, netsD = build_nets(case)
+        netG.to(dev)
+        for d in netsD:
+            d.to(dev)
+        tr = T.condGANTrainer(None, None, 256, False, local_rank=0, distributed=True)
+        tr.build(netG, netsD)
+        batch = make_batch(case)
+        b = {k: ([t.to(dev) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+                 (v.to(dev) if torch.is_tensor(v) else v)) for k, v in batch.items()}
+        for it in range(2):
+            out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], b['noise'],
+                                b['eps'])
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(o).all()) for o in out)
+        flats = [tr.flatG] + tr.flatsD
+        mine = torch.cat([f.p.detach().cpu().view(-1)[::97] for f in flats] + [tr.flatG.avg.detach().cpu().view(-1)[::97]])
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(gathered, mine)
+        assert all(torch.equal(gathered[0], g) for g in gathered), "replicas diverged after two data-parallel steps"
+        # the ranks really saw different data: their losses differ
+        losses = torch.tensor([float(o) for o in out], dtype=torch.float64)
+        gl = [torch.zeros_like(losses) for _ in range(world)]
+        torch.distributed.all_gather(gl, losses)
+        assert not torch.equal(gl[0], gl[1])
+        with open(os.path.join(out_dir, "ok%d" % rank), "w") as fh:
+            fh.write("ok")
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_stay_identical(gpu, tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
