@@ -107,11 +107,16 @@ _D_TOWER = {
     64: (),
     128: (('img_code_s32', 2), ('img_code_s32_1', 1)),
     256: (('img_code_s32', 2), ('img_code_s64', 2), ('img_code_s64_1', 1), ('img_code_s64_2', 1)),
+    # D_NET512 / D_NET1024 (model.py:555-613, 616-672): three / four downBlocks, then Block3x3_leakRelu back to 8 ndf
+    512: (('img_code_s32', 2), ('img_code_s64', 2), ('img_code_s128', 2), ('img_code_s128_1', 1), ('img_code_s128_2', 1),
+          ('img_code_s128_3', 1)),
+    1024: (('img_code_s32', 2), ('img_code_s64', 2), ('img_code_s128', 2), ('img_code_s256', 2), ('img_code_s256_1', 1),
+           ('img_code_s256_2', 1), ('img_code_s256_3', 1), ('img_code_s256_4', 1)),
 }
 
 
 def d_forward(p, size, x, c, training=True):
-    """D_NET64/128/256.forward (model.py:424-445, 473-496, 526-551) -> ([cond, uncond], x_immediate)."""
+    """D_NET64/128/256/512/1024.forward (model.py:424-445, 473-496, 526-551, 584-613, 648-672) -> ([cond, uncond], x_immediate)."""
     h = F.leaky_relu(F.conv2d(x, p['img_code_s16.0.weight'], stride=2, padding=1), 0.2)  # model.py:383-384
     for ci in (2, 5, 8):
         h = F.conv2d(h, p['img_code_s16.%d.weight' % ci], stride=2, padding=1)

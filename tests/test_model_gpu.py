@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, assert_close, assert_close_l2, build_nets, load_golden, make_batch, oracle_dims, sample
+from helpers import CASES, assert_close, assert_close_l2, build_nets, configure, load_golden, make_batch, oracle_dims, sample
 
 pytestmark = pytest.mark.gpu
 
@@ -559,3 +559,28 @@ def test_bf16_product_mode_tracks_fp32(gpu):
     for a, c in zip(res[0][1], res[1][1]):
         rel = float((a - c).norm() / a.norm())
         assert rel < 0.03, rel
+
+
+@pytest.mark.parametrize("size", [512, 1024])
+def test_d_net512_1024_against_reference_golden(gpu, size):
+    """D_NET512 / D_NET1024 on the HIP kernels against outputs of the reference's own classes
+    (tests/golden/dbig.npz): probabilities, x_immediate and the gradient w.r.t. the image."""
+    from test_oracle_golden import DBIG_CASE, _dbig_inputs
+    from speech_to_image_translation_without_text_amd import model, trainer as T
+    gold = load_golden("dbig")
+    configure(DBIG_CASE)
+    torch.manual_seed(DBIG_CASE['seed'] + size)
+    net = {512: model.D_NET512, 1024: model.D_NET1024}[size]()
+    net.apply(T.weights_init)
+    net.to(gpu)
+    x, c = _dbig_inputs(size)
+    xg = x.to(gpu).requires_grad_(True)
+    (cond, uncond), feat = net(xg, c.to(gpu))
+    (cond.sum() + uncond.sum()).backward()
+    torch.cuda.synchronize()
+    assert_close(cond, gold['d%d_cond' % size], rtol=1e-3, atol=1e-5, what="cond")
+    assert_close(uncond, gold['d%d_uncond' % size], rtol=1e-3, atol=1e-5, what="uncond")
+    assert_close(feat, gold['d%d_feat' % size], rtol=1e-3, atol=1e-4, what="x_immediate")
+    assert_close_l2(xg.grad[:, :, ::61, ::53], torch.from_numpy(gold['d%d_dx_sample' % size]), 2e-2, what="dx")
+    s, a = float(xg.grad.double().sum()), float(xg.grad.double().abs().sum())
+    assert abs(a - float(gold['d%d_dx_sum' % size][1])) <= 2e-2 * a, (s, a)
