@@ -6,7 +6,7 @@ product path (speech_to_image_translation_without_text_amd/) never does and has 
 It restates, as pure functions over a {state_dict key: tensor} mapping and stock torch fp32 CPU
 ops, the algorithm of the reference's hot path:
   generator        StackGAN_v2/model.py:112-354   (GLU, upBlock, ResBlock, CA_NET, INIT/NEXT_STAGE_G, G_NET)
-  discriminators   StackGAN_v2/model.py:358-551   (encode_image_by_16times, downBlock, D_NET64/128/256)
+  discriminators   StackGAN_v2/model.py:358-672   (encode_image_by_16times, downBlock, D_NET64/128/256/512/1024)
   losses           StackGAN_v2/trainer.py:54-58 (KL_loss), :298-311 (class_aware_loss)
   D / G updates    StackGAN_v2/trainer.py:375-489 (train_Dnet, train_Gnet), :236-252 (Adam), :571-572 (EMA)
 Parity pin: tests/golden/*.npz hold outputs of the reference itself (imported on CPU in the build

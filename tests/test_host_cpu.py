@@ -36,6 +36,24 @@ def test_descriptor_validation_reports_errors_without_a_gpu():
     assert b"multiples of 4" in lib.s2i_last_error()
     ok = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 8, 0, 16, 0, 0, 8, 16, 0, 1, 16, 1, 0)
     assert lib.s2i_conv_stat_parts(ctypes.byref(ok)) == 1
+    # split-bf16 entry points: eligibility is a host-side rule (gathered channels in whole 32-deep chunks, not the RGB path)
+    thin = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 8, 0, 16, 0, 0, 8, 16, 0, 0, 16, 1, 0)
+    assert lib.s2i_conv_split_eligible(ctypes.byref(thin)) == 0
+    wide = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 64, 0, 128, 0, 0, 64, 128, 0, 1, 128, 1, 0)
+    assert lib.s2i_conv_split_eligible(ctypes.byref(wide)) == 1
+    assert lib.s2i_conv_split_eligible(ctypes.byref(bad)) == 0
+    # weight-gradient planning: same workspace rule in both modes, errors as strings
+    wd = _lib.WgradDesc(_lib.CONV_K3S1, 2, 8, 8, 64, 0, 128, 128, 0, 0, 128, 64, 3, 3, 0, 0, 0)
+    assert lib.s2i_wgrad_workspace_bytes(ctypes.byref(wd)) > 0
+    assert lib.s2i_wgrad_workspace_bytes_split(ctypes.byref(wd), 3) > 0
+    wbad = _lib.WgradDesc(_lib.CONV_K3S1, 2, 6, 6, 64, 0, 128, 128, 0, 0, 128, 64, 3, 3, 0, 0, 0)
+    assert lib.s2i_wgrad_workspace_bytes_split(ctypes.byref(wbad), 3) == 0
+    assert b"powers of two" in lib.s2i_last_error()
+    # compute entry points refuse bad arguments before touching a device
+    assert lib.s2i_conv_forward_split(ctypes.byref(wide), None, None, None, 3, 128, 64, None, None, None, None, None, 0,
+                                      None) != 0
+    assert b"planes" in lib.s2i_last_error()
+    assert lib.s2i_lstm_step(None, 0, None, None, None, 4, 8, 512, 2, 0, None, None, None, None, 0, None) != 0
 
 
 def test_no_cpu_fallback():
