@@ -1,5 +1,6 @@
 """`from datasets import BirdsDataset, FlowersDataset` as the reference's main.py:152-165 does."""
 from speech_to_image_translation_without_text_amd.datasets import (BaseDataset, BirdsDataset, FlowersDataset,  # noqa: F401
+                                                                    PlacesSubSet,
                                                                     default_image_transform, get_imgs,
                                                                     load_embedding_pickle, make_dataloader,
                                                                     save_embedding_pickle)

@@ -311,6 +311,25 @@ class FlowersDataset(BaseDataset):
     """datasets.py:608-642 (`img` key, integer class, no bounding boxes)."""
 
 
+class PlacesSubSet(BaseDataset):
+    """datasets.py:567-605: seven indoor scene classes named by the second path component of `image`
+    ("./<class>/<file>"); `_get_img` drops the leading "./".  The reference's class reads attributes that its base
+    class never sets (`image_embedding`, `prepare_training_pairs`) and cannot run; this follows BaseDataset's working
+    train / test item layout instead."""
+    class_label = {'bedroom': 0, 'dinette': 1, 'dining_room': 2, 'home_office': 3, 'hotel_room': 4,
+                   'kitchenette': 5, 'living_room': 6}
+
+    def __init__(self, data_root, train=True, base_size=64, transform=None, target_transform=None,
+                 feature_switch="cnn_googlenet", device_normalize=False):
+        super().__init__(data_root, train, base_size, transform, target_transform, feature_switch, device_normalize)
+
+    def _get_img(self, item):
+        return item['image'][2:]
+
+    def _get_class(self, item):
+        return self.class_label[item['image'].split("/")[1]]
+
+
 def make_dataloader(dataset, batch_size, distributed=False, workers=0, shuffle=True, rank=None, world_size=None):
     """main.py:166-181: DistributedSampler shards the index set per rank; the default collate turns the per-branch
     image lists into per-branch batches."""

@@ -191,3 +191,26 @@ def test_train_step_from_dataloader_batch(gpu, tmp_path):
         losses.append((float(errD), float(errG), float(kl)))
         assert all(np.isfinite(v) for v in losses[-1])
     assert losses[0] == pytest.approx(losses[1], rel=1e-5)
+
+
+def test_places_subset_labels_and_paths(tmp_path):
+    """datasets.py:567-580: class from the directory name, image path without the leading './'."""
+    configure(CASES['full3_fwd'])
+    rng = np.random.RandomState(0)
+    root = str(tmp_path)
+    img_root = os.path.join(root, "images")
+    names = ['bedroom', 'kitchenette', 'living_room', 'bedroom']
+    items = []
+    for i, cls in enumerate(names):
+        os.makedirs(os.path.join(img_root, cls), exist_ok=True)
+        Image.fromarray(rng.randint(0, 256, (80, 100, 3), dtype=np.uint8)).save(os.path.join(img_root, cls, "%d.png" % i))
+        items.append({"image": "./%s/%d.png" % (cls, i), "class": cls, "audio": [], "text": []})
+    for split in ("train", "test"):
+        with open(os.path.join(root, split + ".json"), "w") as fp:
+            json.dump({"image_base_path": img_root, "audio_base_path": "", "data": items}, fp)
+        D.save_embedding_pickle(rng.randn(4, 10, 8).astype(np.float32),
+                                os.path.join(root, split, "audio_features_cnn_googlenet.pickle"))
+    ds = D.PlacesSubSet(root, train=True, transform=D.default_image_transform(256))
+    real, wrong, e, path, label = ds[1]
+    assert path == "kitchenette/1.png" and label == 5 and e.shape == (8,) and real[2].shape == (3, 256, 256)
+    assert [ds._get_class(it) for it in ds.json_data] == [0, 5, 6, 0]
