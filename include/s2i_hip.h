@@ -184,7 +184,7 @@ int s2i_pack_conv_weights_batched(const s2i_pack_item* items_dev, int n, int tot
  */
 int s2i_bn_finalize(const float* part, int nparts, int groups, int C, long long count, const float* gamma,
                     const float* beta, float* running_mean, float* running_var,
-                    long long* num_batches_tracked /* int64, += 1; may be NULL */, float momentum,
+                    long long* num_batches_tracked /* int64, += groups (one per stacked batch); may be NULL */, float momentum,
                     float eps, float* out4, void* stream);
 /* eval-mode BatchNorm: scale/shift from the running statistics (trainer.py:681-803 path) */
 int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, const float* running_mean,

@@ -9,6 +9,7 @@ ops, the algorithm of the reference's hot path:
   discriminators   StackGAN_v2/model.py:358-672   (encode_image_by_16times, downBlock, D_NET64/128/256/512/1024)
   losses           StackGAN_v2/trainer.py:54-58 (KL_loss), :298-311 (class_aware_loss)
   D / G updates    StackGAN_v2/trainer.py:375-489 (train_Dnet, train_Gnet), :236-252 (Adam), :571-572 (EMA)
+  colour loss      StackGAN_v2/trainer.py:34-51, 455-478 (compute_mean_covariance, like_mu / like_cov terms)
 Parity pin: tests/golden/*.npz hold outputs of the reference itself (imported on CPU in the build
 container by tests/golden/make_golden.py, which also asserts this file against it); this file is
 checked against those vectors by tests/test_oracle_golden.py.
@@ -85,6 +86,32 @@ def get_image(p, prefix, h):  # model.py:287-298
     return torch.tanh(F.conv2d(h, p[prefix + '.img.0.weight'], padding=1))
 
 
+def g_forward_nocond(p, z, dims, training=True):
+    """G_NET.forward with cfg.GAN.B_CONDITION = False (model.py:308, 332-336, 229-233, 254-255): no ca_net, the noise
+    itself is the code that NEXT_STAGE_G broadcasts; INIT_STAGE_G's fc sees z only.  -> ([imgs], None, None)."""
+    h = F.linear(z, p['h_net1.fc.0.weight'])
+    h = glu(_bn(p, 'h_net1.fc.1', h, training)).view(-1, dims.gf_dim * 16, 4, 4)
+    for i in range(1, 5):
+        h = up_block(p, 'h_net1.upsample%d' % i, h, training)
+    imgs = [get_image(p, 'img_net1', h)]
+    for i in range(2, dims.branch_num + 1):
+        h = next_stage(p, 'h_net%d' % i, h, z, dims.r_num, training)
+        imgs.append(get_image(p, 'img_net%d' % i, h))
+    return imgs, None, None
+
+
+def d_forward_nocond(p, size, x, training=True):
+    """D_NETxx.forward with cfg.GAN.B_CONDITION = False (model.py:418, 430-445): no jointConv, one head."""
+    h = F.leaky_relu(F.conv2d(x, p['img_code_s16.0.weight'], stride=2, padding=1), 0.2)
+    for ci in (2, 5, 8):
+        h = F.conv2d(h, p['img_code_s16.%d.weight' % ci], stride=2, padding=1)
+        h = F.leaky_relu(_bn(p, 'img_code_s16.%d' % (ci + 1), h, training), 0.2)
+    for name, stride in _D_TOWER[size]:
+        h = _leaky_block(p, name, h, stride, training)
+    out = torch.sigmoid(F.conv2d(h, p['logits.0.weight'], p['logits.0.bias'], stride=4)).view(-1)
+    return [out], h.reshape(h.shape[0], -1)
+
+
 def g_forward(p, z, emb, eps, dims, training=True):
     """G_NET.forward (model.py:327-354) -> ([img64, img128, img256], mu, logvar)."""
     c, mu, logvar = ca_net(p, emb, eps, dims.ef_dim)
@@ -97,10 +124,34 @@ def g_forward(p, z, emb, eps, dims, training=True):
     return imgs, mu, logvar
 
 
-def _leaky_block(p, prefix, x, stride, training=True):  # model.py:358-376
+class MaskTape:
+    """LeakyReLU decisions of one discriminator forward, in call order.  `record` mode stores `z > 0` of every
+    LeakyReLU; `replay` mode applies the stored decisions instead of the sign of z.  Test instrument: the fused GPU
+    path and this CPU path see pre-activations that differ by ~1e-6, so a z that close to zero can take different
+    sides of the kink; replaying the GPU's decisions here isolates that effect from arithmetic differences."""
+
+    def __init__(self, masks=None):
+        self.masks = [] if masks is None else list(masks)
+        self.replay = masks is not None
+        self.pos = 0
+
+    def lrelu(self, z):
+        if not self.replay:
+            self.masks.append((z > 0).detach())
+            return F.leaky_relu(z, 0.2)
+        m = self.masks[self.pos]
+        self.pos += 1
+        return torch.where(m, z, 0.2 * z)
+
+
+def _lrelu(z, tape):
+    return F.leaky_relu(z, 0.2) if tape is None else tape.lrelu(z)
+
+
+def _leaky_block(p, prefix, x, stride, training=True, tape=None):  # model.py:358-376
     k = p[prefix + '.0.weight']
     x = F.conv2d(x, k, stride=stride, padding=1)
-    return F.leaky_relu(_bn(p, prefix + '.1', x, training), 0.2)
+    return _lrelu(_bn(p, prefix + '.1', x, training), tape)
 
 
 _D_TOWER = {
@@ -115,17 +166,18 @@ _D_TOWER = {
 }
 
 
-def d_forward(p, size, x, c, training=True):
-    """D_NET64/128/256/512/1024.forward (model.py:424-445, 473-496, 526-551, 584-613, 648-672) -> ([cond, uncond], x_immediate)."""
-    h = F.leaky_relu(F.conv2d(x, p['img_code_s16.0.weight'], stride=2, padding=1), 0.2)  # model.py:383-384
+def d_forward(p, size, x, c, training=True, tape=None):
+    """D_NET64/128/256/512/1024.forward (model.py:424-445, 473-496, 526-551, 584-613, 648-672) -> ([cond, uncond], x_immediate).
+    `tape` (MaskTape) records or replays the LeakyReLU decisions (test instrument)."""
+    h = _lrelu(F.conv2d(x, p['img_code_s16.0.weight'], stride=2, padding=1), tape)  # model.py:383-384
     for ci in (2, 5, 8):
         h = F.conv2d(h, p['img_code_s16.%d.weight' % ci], stride=2, padding=1)
-        h = F.leaky_relu(_bn(p, 'img_code_s16.%d' % (ci + 1), h, training), 0.2)
+        h = _lrelu(_bn(p, 'img_code_s16.%d' % (ci + 1), h, training), tape)
     for name, stride in _D_TOWER[size]:
-        h = _leaky_block(p, name, h, stride, training)
+        h = _leaky_block(p, name, h, stride, training, tape)
     x_immediate = h.reshape(h.shape[0], -1)
     cc = c.view(c.size(0), -1, 1, 1).repeat(1, 1, 4, 4)
-    hc = _leaky_block(p, 'jointConv', torch.cat((cc, h), 1), 1, training)
+    hc = _leaky_block(p, 'jointConv', torch.cat((cc, h), 1), 1, training, tape)
     cond = torch.sigmoid(F.conv2d(hc, p['logits.0.weight'], p['logits.0.bias'], stride=4)).view(-1)
     uncond = torch.sigmoid(F.conv2d(h, p['uncond_logits.0.weight'], p['uncond_logits.0.bias'], stride=4)).view(-1)
     return [cond, uncond], x_immediate
@@ -143,6 +195,25 @@ def class_aware_loss(x, labels):  # trainer.py:298-311
     if int(pair.sum()) > 0:
         return torch.clamp(scores.mean() - scores[pair].mean(), min=0).div(D).view(1)
     return torch.zeros(1)
+
+
+def compute_mean_covariance(img):  # trainer.py:34-51
+    B, C, H, W = img.shape
+    mu = img.mean(2, keepdim=True).mean(3, keepdim=True)
+    hat = (img - mu.expand_as(img)).view(B, C, H * W)
+    return mu, torch.bmm(hat, hat.transpose(1, 2)) / (H * W)
+
+
+def colour_loss(fakes, coeff):
+    """Colour-consistency terms of train_Gnet (trainer.py:455-478): neighbouring scales' per-image channel means and
+    covariances, the lower scale detached; the covariance term carries the extra factor 5."""
+    total = 0.0
+    for hi, lo in ((-1, -2), (-2, -3)):
+        if len(fakes) >= -lo:
+            mu1, cov1 = compute_mean_covariance(fakes[hi])
+            mu2, cov2 = compute_mean_covariance(fakes[lo].detach())
+            total = total + coeff * F.mse_loss(mu1, mu2) + coeff * 5 * F.mse_loss(cov1, cov2)
+    return total
 
 
 def bce(prob, target):  # nn.BCELoss(), trainer.py:499
@@ -186,7 +257,7 @@ class TrainState:
         self.avg_g = {k: self.g[k].clone() for k in _trainable(self.g)}
 
 
-def train_step(state, batch, dims, lr_g=2e-4, lr_d=2e-4, uncond=1.0, use_cal=True, kl_coeff=2.0):
+def train_step(state, batch, dims, lr_g=2e-4, lr_d=2e-4, uncond=1.0, use_cal=True, kl_coeff=2.0, color_coeff=0.0):
     """One iteration of condGANTrainer.train's loop body (trainer.py:536-572), Inception excluded.
 
     batch: dict(emb, noise, eps, real=[...], wrong=[...], labels).  Returns a dict of losses and the
@@ -207,12 +278,17 @@ def train_step(state, batch, dims, lr_g=2e-4, lr_d=2e-4, uncond=1.0, use_cal=Tru
         real_l, _ = d_forward(dp, size, batch['real'][i], c)
         wrong_l, _ = d_forward(dp, size, batch['wrong'][i], c)
         fake_l, _ = d_forward(dp, size, fakes[i].detach(), c)
-        errD = (bce(real_l[0], 1) + uncond * bce(real_l[1], 1)
-                + bce(wrong_l[0], 0) + uncond * bce(wrong_l[1], 1)      # wrong pairs: uncond target is REAL (:401)
-                + bce(fake_l[0], 0) + uncond * bce(fake_l[1], 0))
+        if uncond > 0:
+            errD = (bce(real_l[0], 1) + uncond * bce(real_l[1], 1)
+                    + bce(wrong_l[0], 0) + uncond * bce(wrong_l[1], 1)      # wrong pairs: uncond target is REAL (:401)
+                    + bce(fake_l[0], 0) + uncond * bce(fake_l[1], 0))
+        else:  # trainer.py:411-412
+            errD = bce(real_l[0], 1) + 0.5 * (bce(wrong_l[0], 0) + bce(fake_l[0], 0))
         keys = _trainable(dp)
-        grads = torch.autograd.grad(errD, [dp[k] for k in keys])
+        grads = torch.autograd.grad(errD, [dp[k] for k in keys], allow_unused=True)
         for k, g in zip(keys, grads):
+            if g is None:  # unused head (UNCOND_LOSS = 0): torch.optim.Adam skips parameters without a gradient
+                continue
             st = state.opt_ds[i].setdefault(k, {})
             adam_update(state.ds[i][k], g, st, lr_d)
         for k in state.ds[i]:
@@ -227,13 +303,17 @@ def train_step(state, batch, dims, lr_g=2e-4, lr_d=2e-4, uncond=1.0, use_cal=Tru
     for i, size in enumerate(sizes):
         dp = dict(state.ds[i])
         logits, feat = d_forward(dp, size, fakes[i], mu)
-        errG = bce(logits[0], 1) + uncond * bce(logits[1], 1)
+        errG = bce(logits[0], 1)
+        if uncond > 0:
+            errG = errG + uncond * bce(logits[1], 1)
         if use_cal:  # the CAL_LOSS coefficient is only a switch (trainer.py:444-446)
             cal_total = cal_total + class_aware_loss(feat, batch['labels'])
         errG_total = errG_total + errG
         out['errG'].append(float(errG))
         for k in state.ds[i]:
             state.ds[i][k] = dp[k]
+    if color_coeff > 0:
+        errG_total = errG_total + colour_loss(fakes, color_coeff)
     kl = kl_loss(mu, logvar) * kl_coeff
     errG_total = errG_total + kl + cal_total
     keys = _trainable(gp)

@@ -131,12 +131,16 @@ class EncodeImageBy16(nn.Sequential):
                        nn.LeakyReLU(0.2, inplace=False)]
         super().__init__(*layers)
 
-    def forward(self, x, groups=1):
+    def forward(self, x, groups=1, taps=None):
         h = ops.ConvAct.apply(x, self[0].weight, None, "k4s2", ACT_LRELU, self[0].out_channels)
+        if taps is not None:
+            taps.append(h)
         for ci in (2, 5, 8):
             bn = self[ci + 1]
             h = ops.ConvBnAct.apply(h, None, self[ci].weight, bn.weight, bn.bias, None, "k4s2", ACT_LRELU,
                                     _bn_state(bn), self.training, groups)
+            if taps is not None:
+                taps.append(h)
         return h
 
 
@@ -195,7 +199,13 @@ class INIT_STAGE_G(nn.Module):
         h = ops.ConvBnAct.apply(z_code.reshape(B, 1, 1, -1), cvec, lin.weight, bn.weight, bn.bias, None, "k1", ACT_GLU,
                                 _bn_state(bn), self.training)
         h = ops.ToNHWC.apply(h.view(B, self.gf_dim, 4, 4), self.gf_dim)
-        for up in (self.upsample1, self.upsample2, self.upsample3, self.upsample4):
+        h = self.upsample1(h)
+        hook = getattr(self, 'after_up1_hook', None)
+        if hook is not None and h.requires_grad:
+            # fires when the gradient of upsample1's output exists, i.e. when every later layer's parameter gradients
+            # have been issued: the data-parallel trainer starts reducing that part of G's flat gradient there
+            h.register_hook(hook)
+        for up in (self.upsample2, self.upsample3, self.upsample4):
             h = up(h)
         return h
 
@@ -310,19 +320,24 @@ class _DNet(nn.Module):
             self.jointConv = Block3x3_leakRelu(ndf * 8 + self.ef_dim, ndf * 8)
             self.uncond_logits = nn.Sequential(nn.Conv2d(ndf * 8, 1, kernel_size=4, stride=4), nn.Sigmoid())
 
-    def forward(self, x_var, c_code=None, groups=1, need_features=True):
+    def forward(self, x_var, c_code=None, groups=1, need_features=True, taps=None):
         """`groups` > 1 (not part of the reference signature): x_var stacks that many independent batches
         along dim 0 — the real / wrong / fake passes of trainer.py:390-392 in one launch per layer — and
-        every BatchNorm keeps separate statistics per batch, updating its running statistics in that order."""
+        every BatchNorm keeps separate statistics per batch, updating its running statistics in that order.
+        `taps` (a list, tests only) receives the NHWC output of every LeakyReLU block in forward order."""
         x = ops.ToNHWC.apply(x_var, 4)
-        x_code = self.img_code_s16(x, groups)
+        x_code = self.img_code_s16(x, groups, taps)
         for name in self._tower:
             x_code = getattr(self, name)(x_code, groups=groups)
+            if taps is not None:
+                taps.append(x_code)
         B, C = x_code.shape[0], x_code.shape[3]
         # the reference flattens an NCHW map (model.py:428): keep that element order for callers
         x_immediate = ops.ToNCHW.apply(x_code, C).reshape(B, -1) if need_features else None
         if self.b_condition and c_code is not None:
             h_c_code = self.jointConv(x_code, cvec=c_code.reshape(-1, self.ef_dim), groups=groups)
+            if taps is not None:
+                taps.append(h_c_code)
         else:
             h_c_code = x_code
         output = ops.LogitHead.apply(h_c_code, self.logits[0].weight, self.logits[0].bias)

@@ -34,7 +34,29 @@ DIRECT_PARAM_GRAD = False
 
 
 def _direct(p):
-    return DIRECT_PARAM_GRAD and p is not None and p.grad is not None and p.grad.is_contiguous()
+    return (DIRECT_PARAM_GRAD and p is not None and p.requires_grad and p.grad is not None
+            and p.grad.is_contiguous())
+
+
+class param_grad_mode:
+    """Scope of the two module-level switches: `with param_grad_mode(direct=True): ...` turns the direct
+    accumulation into `.grad` (and, optionally, the companion weight-gradient streams) on for the body and restores
+    the previous values afterwards, so a later stock-optimiser use of the same modules in this process sees the
+    default (autograd-returned gradients)."""
+
+    def __init__(self, direct=True, wgrad_side_stream=False):
+        self.new = (bool(direct), bool(wgrad_side_stream))
+
+    def __enter__(self):
+        global DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM
+        self.old = (DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM)
+        DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM = self.new
+        return self
+
+    def __exit__(self, *exc):
+        global DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM
+        DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM = self.old
+        return False
 
 
 # In direct mode the weight-gradient GEMMs are off the backward critical path (nothing downstream reads them
@@ -200,6 +222,20 @@ def split_weight(packed, planes, transpose):
     return cache[3] if transpose else cache[2]
 
 
+# ---- executed-work accounting ------------------------------------------------------------------------
+# bench.py / tools set EXEC_LOG to a list for the duration of ONE step: every matrix-product launch appends
+# (what, flops, bytes) with the multiply-add count the kernels really execute (2*M*N*K of the launched GEMM: up-blocks at
+# 4 taps per output parity, folded c_code channels and skipped weight gradients NOT counted) and the operand + result
+# bytes of the launch.  None (default) costs one comparison per launch.
+EXEC_LOG = None
+_TAPS = {CONV_K1: 1, CONV_K3S1: 9, CONV_K4S2: 16, TCONV_K4S2: 4}
+
+
+def _log_exec(what, M, N, K, in_elems, w_elems, out_elems, esize_in=4, esize_out=4):
+    if EXEC_LOG is not None:
+        EXEC_LOG.append((what, 2.0 * M * N * K, in_elems * esize_in + w_elems * esize_in + out_elems * esize_out, M, N, K))
+
+
 # ---- raw kernels ------------------------------------------------------------------------------------
 def _geom(kind, H, W):
     if kind == CONV_K4S2:
@@ -224,6 +260,11 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
     d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
                  1 if cls_bias is not None else 0, kw1, st1, pd1)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
+    if EXEC_LOG is not None:
+        T = kw1 if conv1d is not None else _TAPS[kind]
+        # TCONV: Ho x Wo is the full-resolution output grid and every output pixel sees 4 taps
+        _log_exec("conv k%d %s[%d,%d,%d,%d+%d]->%d" % (kind, "T" if wmode else "", B, H, W, Cx, Cc, N), B * Ho * Wo, N,
+                  T * (Cx + Cc), x.numel(), T * (Cx + Cc) * N * (4 if kind == TCONV_K4S2 else 1), y.numel())
     part, nparts = None, 0
     if stats:
         nparts = lib.s2i_conv_stat_parts(ctypes.byref(d))
@@ -260,6 +301,10 @@ def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumul
     else:
         O, I, KH, KW = grad_shape
     d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0, i_off, I_total)
+    if EXEC_LOG is not None:
+        Ho, Wo = _geom(kind, H, W)
+        _log_exec("wgrad k%d a[%d,%d,%d,%d+%d] g%d" % (kind, B, H, W, Ca, Cc, N), B * Ho * Wo, N, _TAPS[kind] * (Ca + Cc),
+                  a.numel(), g.numel(), _TAPS[kind] * (Ca + Cc) * N)
     if out is None:
         full = grad_shape if not I_total else (O, I_total, KH, KW)
         out = torch.empty(full, dtype=torch.float32, device=a.device)
@@ -442,9 +487,13 @@ class ConvBnAct(torch.autograd.Function):
         check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ctx.act, ptr(part), nparts,
                                         stream()), "s2i_bn_act_bwd_reduce")
         beta = ctx.beta_ref
-        direct_bn = _direct(gamma) and _direct(beta)
-        dgamma = gamma.grad if direct_bn else torch.empty_like(gamma)
-        dbeta = beta.grad if direct_bn else torch.empty_like(gamma)
+        need_gb = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        direct_bn = need_gb and _direct(gamma) and _direct(beta)
+        if not need_gb:       # frozen BatchNorm parameters (the discriminators during the G update)
+            dgamma = dbeta = None
+        else:
+            dgamma = gamma.grad if direct_bn else torch.empty_like(gamma)
+            dbeta = beta.grad if direct_bn else torch.empty_like(gamma)
         red2 = torch.empty((G, 2, Cout), dtype=torch.float32, device=y.device)
         check(lib.s2i_bn_bwd_finalize(ptr(part), nparts, G, Cout, M // G, ptr(dgamma), ptr(dbeta),
                                       1 if direct_bn else 0, ptr(red2), stream()), "s2i_bn_bwd_finalize")
@@ -722,10 +771,17 @@ class ClassAwareLoss(torch.autograd.Function):
     def backward(ctx, g):
         feats, dS = ctx.saved_tensors
         B, D = feats.shape
-        if B % 4 != 0:
-            raise _lib.S2IError("ClassAwareLoss.backward: batch must be a multiple of 4")
-        # dX = dS_sym X : K1 conv with gathered operand dS (B x B) and weights X used as P[k][n]
-        dX, _, _ = conv_raw(CONV_K1, dS.view(B, 1, 1, B), None, feats, D, wmode=0, wR=B, ldw=D)
+        Bp = _roundup4(B)
+        if Bp != B:
+            # the gathered operand needs a channel count that is a multiple of 4: zero columns of dS against zero
+            # rows of X are exact (ragged last batch of an epoch, trainer.py:543-545: 8855 % 24 = 23 on CUB)
+            dS_p = dS.new_zeros((B, Bp))
+            dS_p[:, :B] = dS
+            feats_p = feats.new_zeros((Bp, D))
+            feats_p[:B] = feats
+            dS, feats = dS_p, feats_p
+        # dX = dS_sym X : K1 conv with gathered operand dS (B x Bp) and weights X used as P[k][n]
+        dX, _, _ = conv_raw(CONV_K1, dS.view(B, 1, 1, Bp), None, feats, D, wmode=0, wR=Bp, ldw=D)
         dX = dX.view(B, D)
         lib = _lib_ready()
         # scale by the incoming gradient, read on the device (no host sync)

@@ -189,6 +189,13 @@ class _LegacyOptimizer:
         self.flat = flat
 
     def step(self):
+        # torch's own `net.zero_grad()` (set_to_none) detaches the parameters' .grad views from the flat gradient
+        # buffer; stepping then would apply stale zeros.  Refuse instead of silently not training.
+        f = self.flat
+        for p, o in zip(f.params, f.offsets):
+            if p.grad is None or p.grad.data_ptr() != f.g.data_ptr() + 4 * o:
+                raise RuntimeError("optimizer.step(): a parameter's .grad no longer aliases the flat gradient buffer "
+                                   "(was net.zero_grad(set_to_none=True) called?); use optimizer.zero_grad()")
         self.flat.adam()
 
     def zero_grad(self):
@@ -260,6 +267,12 @@ class condGANTrainer(object):
                 if f.avg is not None:
                     f.avg.copy_(f.p)
                 ops.refresh_packed(f.params)
+                # DDP(broadcast_buffers=True) (trainer.py:167, 192): a resumed rank-0 checkpoint propagates its
+                # BatchNorm running statistics too
+                for buf in f.net.buffers():
+                    torch.distributed.broadcast(buf, 0)
+            self.rank = torch.distributed.get_rank()
+            self._install_g_overlap()
         self.avg_param_G = self.flatG.avg_params()
         return start_count
 
@@ -280,11 +293,36 @@ class condGANTrainer(object):
         return imgs, real_vimgs, wrong_vimgs, vembedding, class_labels
 
     # -- communication ------------------------------------------------------------------------------------------
-    def _reduce_async(self, flat):
+    def _reduce_async(self, flat, lo=0, hi=None):
         if not self.distributed:
             return None
         ops.join_wgrad_streams()  # the flat gradient buffer must be complete before it is reduced
-        return torch.distributed.all_reduce(flat.g, op=torch.distributed.ReduceOp.SUM, async_op=True)
+        g = flat.g if (lo == 0 and hi is None) else flat.g[lo:hi]
+        return torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, async_op=True)
+
+    def _install_g_overlap(self):
+        """G's gradient all-reduce in two contiguous chunks: everything behind INIT_STAGE_G.upsample1 in parameter
+        order (upsample2..4, the image heads, stages 2 and 3: their backward is complete when the gradient of
+        upsample1's output exists) is reduced while upsample1 / fc / ca_net -- 80 % of G's parameters, last in the
+        backward -- are still computing; the head chunk follows the backward.  Same sums as one all-reduce."""
+        g = _unwrap(self.netG)
+        h1 = getattr(g, 'h_net1', None)
+        self._g_split, self._g_tail_work = None, None
+        if h1 is None or os.environ.get("S2I_G_OVERLAP", "1") != "1":
+            return
+        ids = {id(p): k for k, p in enumerate(self.flatG.params)}
+        first_tail = ids.get(id(h1.upsample2[1].weight))
+        if first_tail is None:
+            return
+        self._g_split = self.flatG.offsets[first_tail]
+
+        def hook(grad):
+            if self._g_hook_armed:
+                self._g_hook_armed = False
+                self._g_tail_work = self._reduce_async(self.flatG, self._g_split, None)
+            return None
+        h1.after_up1_hook = hook
+        self._g_hook_armed = False
 
     # -- D update (trainer.py:375-427) ----------------------------------------------------------------------------
     def _d_logits(self, idx):
@@ -393,21 +431,35 @@ class condGANTrainer(object):
                             + coef * 5 * nn.functional.mse_loss(cov1, cov2)
             kl_loss = KL_loss(self.mu, self.logvar) * cfg.TRAIN.COEFF.KL
             errG_total = errG_total + kl_loss + errG_cal_total
+            split = getattr(self, '_g_split', None) if self.distributed else None
+            self._g_tail_work = None
+            self._g_hook_armed = split is not None
             errG_total.backward()
+            self._g_hook_armed = False
         finally:
             for f in self.flatsD:
                 f.set_requires_grad(True)
-        work = self._reduce_async(self.flatG)
-        if work is not None:
+        if self.distributed and self._g_tail_work is not None:
+            work = self._reduce_async(self.flatG, 0, split)   # head chunk: ca_net, fc, upsample1
             work.wait()
+            self._g_tail_work.wait()
+            self._g_tail_work = None
+        else:
+            work = self._reduce_async(self.flatG)
+            if work is not None:
+                work.wait()
         self.flatG.adam(1.0 / self.world)
         return kl_loss, errG_total
 
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
-        ops.DIRECT_PARAM_GRAD = True  # kernels accumulate into the flat gradient buffers (zeroed per update)
-        # opt-in (S2I_WGRAD_STREAM=1): a rejected experiment, slower than the default
-        ops.WGRAD_SIDE_STREAM = self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"
+        # kernels accumulate into the flat gradient buffers (zeroed per update); the switches are scoped to the step, so
+        # a later stock-optimiser use of the modules in this process gets autograd-returned gradients again.
+        # S2I_WGRAD_STREAM=1 is a rejected experiment, slower than the default.
+        with ops.param_grad_mode(True, self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"):
+            return self._train_step(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
+
+    def _train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
         self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
@@ -465,7 +517,11 @@ class condGANTrainer(object):
 
     def save(self, count):
         """The reference overwrites G's live weights with the EMA copy when it saves and never restores
-        them (trainer.py:256, 590-601); the live weights are kept here."""
+        them (trainer.py:256, 590-601); the live weights are kept here.  With data-parallel ranks only
+        rank 0 writes (the reference lets every rank write the same file names: a race on a shared filesystem); its
+        BatchNorm buffers are the ones kept, as DDP's broadcast_buffers would leave them."""
+        if self.distributed and torch.distributed.get_rank() != 0:
+            return
         live = self.flatG.p.clone()
         save_model(self.netG, self.avg_param_G, self.netsD, count, self.model_dir)
         self.flatG.p.copy_(live)

@@ -64,3 +64,54 @@ def test_two_ranks_on_one_gpu_stay_identical(gpu, tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    """World-size-1 `nccl` (= RCCL) process group, created before any other GPU call: the collectives of the data-parallel
+    step (rank-0 broadcast of parameters and BatchNorm buffers, per-network flat all-reduce issued from the discriminator
+    streams, the two-chunk G all-reduce started from a backward hook) run through RCCL itself, and must leave the result
+    bit-identical to the non-distributed step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    dev = torch.device("cuda:0")
+    torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from helpers import CASES, build_nets, make_batch
+        from speech_to_image_translation_without_text_amd import trainer as T
+        torch.cuda.set_device(0)
+        case = dict(CASES["small3"], B=8)
+        batch = make_batch(case)
+        b = {k: ([t.to(dev) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
+                 (v.to(dev) if torch.is_tensor(v) else v)) for k, v in batch.items()}
+        finals = []
+        for distributed in (True, False):
+            netG, netsD = build_nets(case)
+            netG.to(dev)
+            for d in netsD:
+                d.to(dev)
+            tr = T.condGANTrainer(None, None, 256, False, local_rank=0, distributed=distributed)
+            tr.build(netG, netsD)
+            if distributed:
+                assert tr._g_split is not None and 0 < tr._g_split < tr.flatG.total
+            for it in range(2):
+                out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'],
+                                    b['noise'], b['eps'])
+            torch.cuda.synchronize()
+            finals.append([f.p.clone() for f in [tr.flatG] + tr.flatsD] + [tr.flatG.avg.clone(), tr.flatG.m.clone()]
+                          + [torch.stack([o.detach().reshape(()) for o in out])])
+        for a, c in zip(*finals):
+            assert torch.equal(a, c), "the RCCL path changed the result of a world-size-1 step"
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        with open(os.path.join(out_dir, "ok%d" % rank), "w") as fh:
+            fh.write("ok rccl %s" % ver)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world_size_one_rccl_group_matches_single_process(gpu, tmp_path):
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
+    print((tmp_path / "ok0").read_text())

@@ -123,3 +123,70 @@ def test_oracle_d512_d1024_match_reference(size):
     assert_close(uncond, gold['d%d_uncond' % size], rtol=1e-4, atol=1e-6, what="uncond")
     assert_close(feat, gold['d%d_feat' % size], rtol=1e-4, atol=1e-5, what="x_immediate")
     assert_close(x.grad[:, :, ::61, ::53], gold['d%d_dx_sample' % size], rtol=1e-3, atol=1e-7, what="dx")
+
+
+# ---- dormant configuration branches (tests/golden/variants.npz, from the reference's own code) -----------------------
+@pytest.mark.parametrize("tag,kw", [("color", dict(color_coeff=1.0)), ("nouncond", dict(uncond=0.0))])
+def test_oracle_variant_steps(tag, kw):
+    """COLOR_LOSS = 1 (trainer.py:455-478) and UNCOND_LOSS = 0 (trainer.py:411-412, 439-443) through the oracle's full
+    iteration, against the reference's own train_Dnet / train_Gnet outputs."""
+    case, gold = CASES['small3'], load_golden('variants')
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    batch['eps'] = torch.from_numpy(gold[tag + '/eps'])
+    state = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    out = orc.train_step(state, batch, oracle_dims(case), **kw)
+    assert_close(np.asarray(out['errD']), gold[tag + '/errD'], rtol=2e-4, atol=1e-5, what="errD")
+    assert_close(out['errG_total'], float(gold[tag + '/errG_total']), rtol=2e-4, atol=1e-5, what="errG_total")
+    assert_close(out['kl'], float(gold[tag + '/kl']), rtol=2e-4, atol=1e-6, what="kl")
+    assert_close(out['grad_emb'], gold[tag + '/grad_emb'], rtol=1e-3, atol=1e-6, what="grad_emb")
+    for key in gold.files:
+        if key.startswith(tag + '/g_grad/'):
+            k = key[len(tag) + 8:]
+            assert_close(sample(out['grad_g'][k]), gold[key], rtol=1e-3, atol=1e-6, what=key)
+
+
+def test_oracle_mean_covariance_matches_reference():
+    gold = load_golden('variants')
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(3, 3, 8, 16, generator=g) * 2 - 1
+    mu, cov = orc.compute_mean_covariance(img)
+    assert_close(mu, gold['meancov/mu'], rtol=1e-6, atol=1e-7, what="mu")
+    assert_close(cov, gold['meancov/cov'], rtol=1e-6, atol=1e-7, what="cov")
+
+
+def test_oracle_and_construction_without_condition():
+    """cfg.GAN.B_CONDITION = False (model.py:308, 332-336, 418, 430-445): no ca_net / jointConv / second head; seeded
+    construction equals the reference's, the oracle's forwards equal the reference's outputs."""
+    from speech_to_image_translation_without_text_amd import model, trainer
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
+    case, gold = CASES['small3'], load_golden('variants')
+    configure(case)
+    cfg.GAN.B_CONDITION = False
+    try:
+        torch.manual_seed(case['seed'])
+        netG = model.G_NET()
+        netG.apply(trainer.weights_init)
+        netsD = []
+        for cls in (model.D_NET64, model.D_NET128, model.D_NET256):
+            d = cls()
+            d.apply(trainer.weights_init)
+            netsD.append(d)
+    finally:
+        cfg.GAN.B_CONDITION = True
+    assert list(netG.state_dict().keys()) == [str(k) for k in gold['nocond/g_keys']]
+    assert not any(k.startswith('ca_net') for k in netG.state_dict())
+    np.testing.assert_allclose(checksum(netG.state_dict()), gold['nocond/g_checksum'], rtol=0, atol=0)
+    batch = make_batch(case)
+    fakes, mu, logvar = orc.g_forward_nocond({k: v.clone() for k, v in netG.state_dict().items()}, batch['noise'],
+                                             oracle_dims(case))
+    assert mu is None and logvar is None
+    for i, d in enumerate(netsD):
+        assert list(d.state_dict().keys()) == [str(k) for k in gold['nocond/d%d_keys' % i]]
+        assert not any(k.startswith('jointConv') or k.startswith('uncond') for k in d.state_dict())
+        np.testing.assert_allclose(checksum(d.state_dict()), gold['nocond/d%d_checksum' % i], rtol=0, atol=0)
+        assert_close(sample(fakes[i], 16384), gold['nocond/fake%d_sample' % i], what="fake%d" % i)
+        logits, feat = orc.d_forward_nocond({k: v.clone() for k, v in d.state_dict().items()}, 64 << i, fakes[i])
+        assert len(logits) == 1
+        assert_close(logits[0], gold['nocond/d%d_logit' % i], what="logit%d" % i)
+        assert_close(sample(feat), gold['nocond/d%d_feat_sample' % i], what="feat%d" % i)

@@ -1,0 +1,491 @@
+"""Segmented gradient parity and the dormant configuration branches, on a real MI355X.
+
+The end-to-end gradient comparison of test_model_gpu.py is norm-wise because it crosses the discriminators'
+LeakyReLU kinks.  Here the chain is cut where the kinks are:
+  * G alone has no kinks (GLU, tanh, BatchNorm): given the SAME dL/dfake on both sides its backward must agree
+    element-wise;
+  * D alone, from identical images and weights: the LeakyReLU decisions that differ from the oracle's are counted, and the
+    oracle's backward replayed with the GPU's decisions must agree element-wise with the GPU's gradients;
+  * the same at a non-initial operating point (after tens of updates: saturated heads, BCE near its clamp, BatchNorm
+    channels with |mean| >> std).
+Tolerance everywhere: rtol 1e-3 with an absolute floor relative to the tensor's largest reference value.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import CASES, assert_close, assert_close_l2, build_nets, configure, load_golden, make_batch, oracle_dims, sample
+
+pytestmark = pytest.mark.gpu
+
+SIZES = (64, 128, 256)
+
+
+def to_dev(batch, dev):
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v):
+            out[k] = v.to(dev)
+        elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+            out[k] = [t.to(dev) for t in v]
+        else:
+            out[k] = v
+    return out
+
+
+def assert_close_scaled(got, want, rtol=1e-3, floor=1e-4, what=""):
+    """|got - want| <= rtol * |want| + floor * max|want|, element-wise."""
+    got = torch.as_tensor(got).detach().cpu().double()
+    want = torch.as_tensor(want).detach().cpu().double()
+    assert got.shape == want.shape, (what, tuple(got.shape), tuple(want.shape))
+    scale = float(want.abs().max())
+    err = (got - want).abs()
+    bad = err > rtol * want.abs() + floor * scale
+    assert not bool(bad.any()), "%s: max abs err %.3e (scale %.3e), %d/%d beyond rtol=%g floor=%g*max" % (
+        what, float(err.max()), scale, int(bad.sum()), bad.numel(), rtol, floor)
+    return float(err.max()) / (scale + 1e-300)
+
+
+def _oracle_g_loss_grads(ostate_g, ds, batch, dims, with_cal=True):
+    """Oracle: G forward; then, CUT at (fake images, mu, logvar), the three discriminator forwards and the G loss give
+    dL/dfake_i and the direct dL/dmu, dL/dlogvar (discriminator condition + KL); from those, G's backward alone gives the
+    gradient of every G parameter and of the embedding."""
+    from oracle import stackgan_oracle as orc
+    gp = orc._with_grad(ostate_g)
+    emb = batch['emb'].detach().clone().requires_grad_(True)
+    fakes, mu, logvar = orc.g_forward(gp, batch['noise'], emb, batch['eps'], dims)
+    cut = [f.detach().clone().requires_grad_(True) for f in fakes]
+    mu_c, lv_c = mu.detach().clone().requires_grad_(True), logvar.detach().clone().requires_grad_(True)
+    total = orc.kl_loss(mu_c, lv_c) * 2.0
+    for i in range(dims.branch_num):
+        logits, feat = orc.d_forward(dict(ds[i]), SIZES[i], cut[i], mu_c)
+        total = total + orc.bce(logits[0], 1) + orc.bce(logits[1], 1)
+        if with_cal:
+            total = total + orc.class_aware_loss(feat, batch['labels']).reshape(())
+    gos = [g.detach() for g in torch.autograd.grad(total, cut + [mu_c, lv_c])]
+    keys = orc._trainable(gp)
+    grads = torch.autograd.grad(list(fakes) + [mu, logvar], [gp[k] for k in keys] + [emb], grad_outputs=gos,
+                                allow_unused=True)
+    return ([f.detach() for f in fakes], gos[:-2], gos[-2], gos[-1], {k: g for k, g in zip(keys, grads[:-1])}, grads[-1])
+
+
+def _g_only_backward_check(netG, ostate_g, ds, batch, dims, gpu, what):
+    fakes_o, dfakes, dmu, dlv, grads_o, gemb_o = _oracle_g_loss_grads(ostate_g, ds, batch, dims)
+    b = to_dev(batch, gpu)
+    emb = b['emb'].clone().requires_grad_(True)
+    for p in netG.parameters():
+        p.grad = None
+    fakes, mu, logvar = netG(b['noise'], emb, b['eps'])
+    for i in range(len(fakes)):
+        assert_close(fakes[i], fakes_o[i], rtol=1e-3, atol=1e-4, what="%s img%d" % (what, i))
+    torch.autograd.backward(list(fakes) + [mu, logvar],
+                            [d.to(gpu) for d in dfakes] + [dmu.to(gpu), dlv.to(gpu)])
+    torch.cuda.synchronize()
+    worst = 0.0
+    named = dict(netG.named_parameters())
+    for k, g in grads_o.items():
+        worst = max(worst, assert_close_scaled(named[k].grad, g, what="%s dG/%s" % (what, k)))
+    worst = max(worst, assert_close_scaled(emb.grad, gemb_o, what=what + " grad_emb"))
+    print("%s: worst element-wise deviation of a G gradient = %.2e of the tensor's max" % (what, worst))
+
+
+def test_generator_backward_elementwise_from_identical_image_gradients(gpu):
+    """G has no kinks: fed the oracle's dL/dfake_i (and the oracle's direct dL/dmu, dL/dlogvar), every G parameter
+    gradient and the embedding gradient hold rtol 1e-3 element-wise (trainer.py:429-489 behind the images)."""
+    from oracle import stackgan_oracle as orc
+    case, gold = CASES['small3'], load_golden('small3')
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    batch['eps'] = torch.from_numpy(gold['eps'])
+    ostate = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    netG.to(gpu)
+    _g_only_backward_check(netG, ostate.g, ostate.ds, batch, oracle_dims(case), gpu, "init")
+
+
+def _d_loss_oracle(dp, size, imgs, c, tape):
+    from oracle import stackgan_oracle as orc
+    real_l, _ = orc.d_forward(dp, size, imgs[0], c, tape=tape)
+    wrong_l, _ = orc.d_forward(dp, size, imgs[1], c, tape=tape)
+    fake_l, _ = orc.d_forward(dp, size, imgs[2], c, tape=tape)
+    return (orc.bce(real_l[0], 1) + orc.bce(real_l[1], 1) + orc.bce(wrong_l[0], 0) + orc.bce(wrong_l[1], 1)
+            + orc.bce(fake_l[0], 0) + orc.bce(fake_l[1], 0))
+
+
+def _d_only_backward_check(netD, sd_cpu, size, imgs, c, gpu, what):
+    """Discriminator gradients from identical images and weights.  Returns the number of LeakyReLU decisions that
+    differ between the GPU forward and the oracle's."""
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import ops
+    # GPU: three separate passes (the reference's structure), autograd-returned gradients, every LeakyReLU output tapped
+    for p in netD.parameters():
+        p.grad = None
+    taps = []
+    crit = nn.BCELoss()
+    B = imgs[0].shape[0]
+    ones, zeros = torch.ones(B, device=gpu), torch.zeros(B, device=gpu)
+    loss = 0
+    for x, (tc, tu) in zip(imgs, ((ones, ones), (zeros, ones), (zeros, zeros))):
+        logits, _ = netD(x.to(gpu), c.to(gpu), taps=taps)
+        loss = loss + crit(logits[0], tc) + crit(logits[1], tu)
+    loss.backward()
+    torch.cuda.synchronize()
+    gpu_masks = [(t.detach() > 0).permute(0, 3, 1, 2).cpu() for t in taps]  # NHWC outputs -> NCHW decisions
+    # oracle, own decisions
+    rec = orc.MaskTape()
+    dp = orc._with_grad(sd_cpu)
+    loss_o = _d_loss_oracle(dp, size, imgs, c, rec)
+    assert len(rec.masks) == len(gpu_masks)
+    flips = sum(int((a != g).sum()) for a, g in zip(rec.masks, gpu_masks))
+    total = sum(a.numel() for a in rec.masks)
+    # oracle, the GPU's decisions
+    dp2 = orc._with_grad({k: v.clone() for k, v in sd_cpu.items()})
+    loss_r = _d_loss_oracle(dp2, size, imgs, c, orc.MaskTape(gpu_masks))
+    keys = orc._trainable(dp2)
+    grads_r = torch.autograd.grad(loss_r, [dp2[k] for k in keys])
+    assert_close(float(loss), float(loss_o), rtol=1e-3, atol=1e-5, what=what + " errD")
+    named = dict(netD.named_parameters())
+    worst = 0.0
+    for k, g in zip(keys, grads_r):
+        worst = max(worst, assert_close_scaled(named[k].grad, g, what="%s dD/%s" % (what, k)))
+    print("%s: %d of %d LeakyReLU decisions differ from the oracle's; with the GPU's decisions replayed the worst "
+          "element-wise gradient deviation is %.2e of the tensor's max" % (what, flips, total, worst))
+    assert flips <= max(4, 2e-4 * total), (what, flips, total)
+    return flips
+
+
+def test_discriminator_backward_explained_by_mask_flips(gpu):
+    """D from identical images and weights (trainer.py:375-427): the oracle's backward with the GPU's LeakyReLU
+    decisions agrees element-wise with the GPU's parameter gradients; the decisions that differ are counted."""
+    from oracle import stackgan_oracle as orc
+    case = CASES['small3']
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    with torch.no_grad():
+        fakes, mu, _ = orc.g_forward({k: v.clone() for k, v in netG.state_dict().items()}, batch['noise'], batch['emb'],
+                                     batch['eps'], oracle_dims(case))
+    for i, d in enumerate(netsD):
+        sd = {k: v.clone() for k, v in d.state_dict().items()}
+        d.to(gpu)
+        _d_only_backward_check(d, sd, SIZES[i], (batch['real'][i], batch['wrong'][i], fakes[i]), mu, gpu, "D%d init" % i)
+
+
+def _export_state(tr, netG, netsD):
+    """HIP trainer state -> oracle TrainState (weights, BatchNorm buffers, Adam moments and step counts, EMA)."""
+    from oracle import stackgan_oracle as orc
+    st = orc.TrainState({k: v.detach().cpu().clone() for k, v in netG.state_dict().items()},
+                        [{k: v.detach().cpu().clone() for k, v in d.state_dict().items()} for d in netsD])
+
+    def adam_state(flat, net):
+        out = {}
+        ids = {id(p): (o, n) for p, o, n in zip(flat.params, flat.offsets, flat.sizes)}
+        for k, p in net.named_parameters():
+            o, n = ids[id(p)]
+            out[k] = dict(step=flat.step_count, m=flat.m[o:o + n].view_as(p).detach().cpu().clone(),
+                          v=flat.v[o:o + n].view_as(p).detach().cpu().clone())
+        return out
+    st.opt_g = adam_state(tr.flatG, netG)
+    st.opt_ds = [adam_state(f, d) for f, d in zip(tr.flatsD, netsD)]
+    avg = tr.avg_param_G
+    st.avg_g = {k: a.detach().cpu().clone() for (k, _), a in zip(netG.named_parameters(), avg)}
+    return st
+
+
+def test_non_initial_operating_point(gpu):
+    """After 60 HIP iterations at `small3` (fresh noise every step) the state is exported into the oracle and ONE more
+    iteration runs on both sides: losses, images, BatchNorm running statistics, plus the segmented gradient checks
+    (G-only element-wise, D-only with replayed decisions) at that operating point."""
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import trainer as T
+    case = dict(CASES['small3'], B=8)
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    netG.to(gpu)
+    for d in netsD:
+        d.to(gpu)
+    tr = T.condGANTrainer(None, None, 256, False)
+    tr.build(netG, netsD)
+    b = to_dev(batch, gpu)
+    g = torch.Generator(device=gpu).manual_seed(1234)
+    hist = []
+    for it in range(60):
+        noise = torch.randn(b['noise'].shape, device=gpu, generator=g)
+        eps = torch.randn(b['eps'].shape, device=gpu, generator=g)
+        out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], noise, eps)
+        if it % 10 == 9:
+            hist.append([round(float(o), 4) for o in out])
+    torch.cuda.synchronize()
+    print("losses (errD, errG, kl) every 10 iterations:", hist)
+    ostate = _export_state(tr, netG, netsD)
+    # how far from the initial regime: BatchNorm channels whose |running_mean| is large against sqrt(running_var)
+    ratios = []
+    for d in netsD:
+        sd = d.state_dict()
+        for k in sd:
+            if k.endswith('running_mean'):
+                ratios.append(float((sd[k].abs() / sd[k.replace('running_mean', 'running_var')].sqrt()).max()))
+    print("max |running_mean| / sqrt(running_var) over the discriminators' BatchNorm layers: %.2f" % max(ratios))
+
+    noise = torch.randn(b['noise'].shape, device=gpu, generator=g)
+    eps = torch.randn(b['eps'].shape, device=gpu, generator=g)
+    obatch = dict(batch, noise=noise.cpu(), eps=eps.cpu())
+    # segmented gradient checks at this operating point, before either side moves
+    sd_snap = [{k: v.clone() for k, v in d.items()} for d in ostate.ds]
+    g_snap = {k: v.clone() for k, v in ostate.g.items()}
+    oout = orc.train_step(ostate, obatch, oracle_dims(case))
+    out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], noise, eps)
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert_close(tr.fake_imgs[i], oout['fake'][i], rtol=1e-3, atol=2e-4, what="img%d after 60 its" % i)
+    assert_close(float(out[0]), oout['errD_total'], rtol=2e-3, atol=1e-4, what="errD_total")
+    assert_close(float(out[1]), oout['errG_total'], rtol=2e-3, atol=1e-4, what="errG_total")
+    assert_close(float(out[2]), oout['kl'], rtol=1e-3, atol=1e-5, what="kl")
+    for net, osd, tag in [(netG, ostate.g, "G")] + [(d, ostate.ds[i], "D%d" % i) for i, d in enumerate(netsD)]:
+        for k, v in net.state_dict().items():
+            if k.endswith('running_mean') or k.endswith('running_var'):
+                assert_close_scaled(v, osd[k], rtol=1e-3, floor=1e-4, what="%s %s after 60 its" % (tag, k))
+            elif k.endswith('num_batches_tracked'):
+                assert int(v) == int(osd[k]), (tag, k)
+
+    # G-only and D-only gradients from the snapshot taken before the last iteration
+    g2, ds2 = build_nets(case)
+    g2.load_state_dict(g_snap)
+    g2.to(gpu)
+    _g_only_backward_check(g2, g_snap, sd_snap, obatch, oracle_dims(case), gpu, "after 60 its")
+    with torch.no_grad():
+        fakes, mu, _ = orc.g_forward({k: v.clone() for k, v in g_snap.items()}, obatch['noise'], obatch['emb'],
+                                     obatch['eps'], oracle_dims(case))
+    for i, d in enumerate(ds2):
+        d.load_state_dict(sd_snap[i])
+        d.to(gpu)
+        _d_only_backward_check(d, sd_snap[i], SIZES[i], (batch['real'][i], batch['wrong'][i], fakes[i]), mu, gpu,
+                               "D%d after 60 its" % i)
+
+
+# ---- dormant configuration branches against the reference's own outputs (tests/golden/variants.npz) -------------------
+def _variant_step(gpu, tag, set_cfg):
+    from speech_to_image_translation_without_text_amd import trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
+    case, gold = CASES['small3'], load_golden('variants')
+    netG, netsD = build_nets(case)
+    set_cfg(cfg)
+    try:
+        batch = make_batch(case)
+        batch['eps'] = torch.from_numpy(gold[tag + '/eps'])
+        netG.to(gpu)
+        for d in netsD:
+            d.to(gpu)
+        tr = T.condGANTrainer(None, None, 256, False)
+        tr.build(netG, netsD)
+        tr.flatG.lr = 0.0  # keep G's gradients readable after the step
+        b = to_dev(batch, gpu)
+        emb = b['emb'].clone().requires_grad_(True)
+        errD, errG, kl = tr.train_step(b['real'], b['wrong'], emb, batch['labels'], b['noise'], b['eps'])
+        torch.cuda.synchronize()
+    finally:
+        configure(case)
+    assert_close(float(errD), float(gold[tag + '/errD'].sum()), rtol=1e-3, atol=1e-4, what=tag + " errD_total")
+    assert_close(float(errG), float(gold[tag + '/errG_total']), rtol=1e-3, atol=1e-4, what=tag + " errG_total")
+    assert_close(float(kl), float(gold[tag + '/kl']), rtol=1e-3, atol=1e-5, what=tag + " kl")
+    assert_close_l2(emb.grad, gold[tag + '/grad_emb'], 6e-2, what=tag + " grad_emb")
+    named = dict(netG.named_parameters())
+    for key in gold.files:
+        if key.startswith(tag + '/g_grad/'):
+            assert_close_l2(sample(named[key[len(tag) + 8:]].grad.cpu()), gold[key], 2e-2, what=key)
+    return tr
+
+
+def test_colour_consistency_loss_against_reference(gpu):
+    """COLOR_LOSS = 1 (trainer.py:34-51, 455-478): the full HIP iteration against the reference's own train_Gnet."""
+    def on(cfg):
+        cfg.TRAIN.COEFF.COLOR_LOSS = 1.0
+    _variant_step(gpu, 'color', on)
+    from speech_to_image_translation_without_text_amd import trainer as T
+    gold = load_golden('variants')
+    g = torch.Generator().manual_seed(11)
+    img = torch.rand(3, 3, 8, 16, generator=g) * 2 - 1
+    mu, cov = T.compute_mean_covariance(img.to(gpu))
+    assert_close(mu, gold['meancov/mu'], rtol=1e-5, atol=1e-6, what="mu")
+    assert_close(cov, gold['meancov/cov'], rtol=1e-5, atol=1e-6, what="cov")
+
+
+def test_unconditional_loss_off_against_reference(gpu):
+    """UNCOND_LOSS = 0: errD = real + 0.5 * (wrong + fake) (trainer.py:411-412), G loss without the unconditional term."""
+    def off(cfg):
+        cfg.TRAIN.COEFF.UNCOND_LOSS = 0.0
+    tr = _variant_step(gpu, 'nouncond', off)
+    # the unconditional heads received no gradient and did not move (torch.optim.Adam skips them in the reference)
+    for f, d in zip(tr.flatsD, tr.netsD):
+        w = dict(d.named_parameters())['uncond_logits.0.weight']
+        assert float(w.grad.abs().max()) == 0.0
+
+
+def test_b_condition_false_against_reference(gpu):
+    """cfg.GAN.B_CONDITION = False (model.py:308, 332-336, 418, 430-445): G and D forwards and the gradient of
+    sum(logits) + <x_immediate, r> w.r.t. the noise and G parameters, against the reference's own classes."""
+    from speech_to_image_translation_without_text_amd import model, trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
+    case, gold = CASES['small3'], load_golden('variants')
+    configure(case)
+    cfg.GAN.B_CONDITION = False
+    try:
+        torch.manual_seed(case['seed'])
+        netG = model.G_NET()
+        netG.apply(T.weights_init)
+        netsD = []
+        for cls in (model.D_NET64, model.D_NET128, model.D_NET256):
+            d = cls()
+            d.apply(T.weights_init)
+            netsD.append(d)
+        batch = make_batch(case)
+        netG.to(gpu)
+        z = batch['noise'].to(gpu).requires_grad_(True)
+        fakes, mu, logvar = netG(z, None)
+        assert mu is None and logvar is None
+        total = 0
+        gr = torch.Generator().manual_seed(5)
+        for i, d in enumerate(netsD):
+            d.to(gpu)
+            logits, feat = d(fakes[i], None)
+            assert len(logits) == 1
+            assert_close(sample(fakes[i].detach().cpu(), 16384), gold['nocond/fake%d_sample' % i], what="fake%d" % i)
+            assert_close(logits[0], gold['nocond/d%d_logit' % i], rtol=1e-3, atol=1e-5, what="logit%d" % i)
+            assert_close(sample(feat.detach().cpu()), gold['nocond/d%d_feat_sample' % i], rtol=1e-3, atol=2e-4,
+                         what="feat%d" % i)
+            r = torch.randn(feat.shape, generator=gr) * 0.01
+            total = total + logits[0].sum() + (feat * r.to(gpu)).sum()
+        total.backward()
+        torch.cuda.synchronize()
+    finally:
+        cfg.GAN.B_CONDITION = True
+    assert_close_l2(z.grad, gold['nocond/grad_z'], 2e-2, what="grad_z")
+    named = dict(netG.named_parameters())
+    for key in gold.files:
+        if key.startswith('nocond/g_grad/'):
+            assert_close_l2(sample(named[key[len('nocond/g_grad/'):]].grad.cpu()), gold[key], 2e-2, what=key)
+
+
+def test_reference_style_trainer_without_flat_buffers(gpu):
+    """the modules driven the way the reference's trainer drives them
+    (trainer.py:375-489): three separate netD(...) calls, nn.BCELoss, torch.optim.Adam(net.parameters()),
+    loss.backward(), optimizer.step() -- no FlatNet, no direct gradient accumulation -- against the `small3` golden."""
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
+    case, gold = CASES['small3'], load_golden('small3')
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    batch['eps'] = torch.from_numpy(gold['eps'])
+    netG.to(gpu)
+    for d in netsD:
+        d.to(gpu)
+    assert ops.DIRECT_PARAM_GRAD is False
+    b = to_dev(batch, gpu)
+    B = case['B']
+    crit = nn.BCELoss()
+    real_labels, fake_labels = torch.ones(B, device=gpu), torch.zeros(B, device=gpu)
+    optG = torch.optim.Adam(netG.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    optsD = [torch.optim.Adam(d.parameters(), lr=2e-4, betas=(0.5, 0.999)) for d in netsD]
+    emb = b['emb'].clone().requires_grad_(True)
+    fake_imgs, mu, logvar = netG(b['noise'], emb, b['eps'])
+    errDs = []
+    for i, netD in enumerate(netsD):
+        netD.zero_grad()
+        real_logits, _ = netD(b['real'][i], mu.detach())
+        wrong_logits, _ = netD(b['wrong'][i], mu.detach())
+        fake_logits, _ = netD(fake_imgs[i].detach(), mu.detach())
+        errD = (crit(real_logits[0], real_labels) + crit(real_logits[1], real_labels)
+                + crit(wrong_logits[0], fake_labels) + crit(wrong_logits[1], real_labels)
+                + crit(fake_logits[0], fake_labels) + crit(fake_logits[1], fake_labels))
+        errD.backward()
+        optsD[i].step()
+        errDs.append(float(errD))
+    netG.zero_grad()
+    errG_total = 0
+    for i, netD in enumerate(netsD):
+        outputs, x_active = netD(fake_imgs[i], mu)
+        errG_total = errG_total + crit(outputs[0], real_labels) + crit(outputs[1], real_labels)
+        errG_total = errG_total + T.class_aware_loss(x_active, batch['labels']).reshape(())
+    kl = T.KL_loss(mu, logvar) * 2.0
+    errG_total = errG_total + kl
+    errG_total.backward()
+    optG.step()
+    torch.cuda.synchronize()
+    assert_close(np.asarray(errDs), gold['errD'], rtol=1e-3, atol=1e-4, what="errD")
+    assert_close(float(errG_total), float(gold['errG_total']), rtol=1e-3, atol=1e-4, what="errG_total")
+    assert_close(float(kl), float(gold['kl']), rtol=1e-3, atol=1e-5, what="kl")
+    assert_close_l2(emb.grad, gold['grad_emb'], 6e-2, what="grad_emb")
+    for i in range(3):
+        assert_close(sample(fake_imgs[i].detach().cpu(), 16384), gold['fake%d_sample' % i], what="fake%d" % i)
+
+    def check_after(got, want, what):
+        err = (torch.as_tensor(got).double() - torch.as_tensor(want).double()).abs()
+        assert float(err.max()) <= 4.2e-4, (what, float(err.max()))
+        assert int((err > 5e-6).sum()) <= max(2, 0.10 * err.numel()), (what, int((err > 5e-6).sum()), err.numel())
+    gsd = netG.state_dict()
+    for key in gold.files:
+        if key.startswith('g_after/') and not key.endswith('running_var'):
+            check_after(sample(gsd[key[len('g_after/'):]].cpu()), gold[key], key)
+        elif key[:2] in ('d0', 'd1', 'd2') and '_after/' in key and not key.endswith('running_mean'):
+            i, k = int(key[1]), key.split('_after/')[1]
+            check_after(sample(netsD[i].state_dict()[k].cpu()), gold[key], key)
+    # a second forward sees the updated weights (the packed copies follow torch's version counter)
+    with torch.no_grad():
+        f2, _, _ = netG(b['noise'], b['emb'], b['eps'])
+    assert float((f2[0] - fake_imgs[0]).abs().max()) > 0
+
+
+@pytest.mark.parametrize("B", [5, 23])
+def test_ragged_batch_full_train_step(gpu, B):
+    """Last batch of an epoch (8855 % 24 = 23 on CUB, trainer.py:543-545; odd DistributedSampler shards): a full
+    iteration with CAL_LOSS > 0 at a batch that is not a multiple of 4 (un-stacked D passes, padded class-aware
+    backward) against the oracle."""
+    from oracle import stackgan_oracle as orc
+    from speech_to_image_translation_without_text_amd import trainer as T
+    case = dict(CASES['small3'], B=B)
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    ostate = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    oout = orc.train_step(ostate, batch, oracle_dims(case))
+    assert oout['cal'] > 0
+    netG.to(gpu)
+    for d in netsD:
+        d.to(gpu)
+    tr = T.condGANTrainer(None, None, 256, False)
+    tr.build(netG, netsD)
+    tr.flatG.lr = 0.0
+    b = to_dev(batch, gpu)
+    emb = b['emb'].clone().requires_grad_(True)
+    errD, errG, kl = tr.train_step(b['real'], b['wrong'], emb, batch['labels'], b['noise'], b['eps'])
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert_close(tr.fake_imgs[i], oout['fake'][i], rtol=1e-3, atol=1e-4, what="img%d B=%d" % (i, B))
+    assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total B=%d" % B)
+    assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total B=%d" % B)
+    assert_close_l2(emb.grad, oout['grad_emb'], 6e-2, what="grad_emb B=%d" % B)
+    named = dict(netG.named_parameters())
+    for k, g in oout['grad_g'].items():
+        assert_close_l2(named[k].grad.cpu(), g, 2e-2, what="dG/%s B=%d" % (k, B))
+
+
+def test_step_scopes_the_direct_gradient_switches(gpu):
+    """train_step turns direct accumulation on for its own duration only: afterwards the module-level
+    switches are back at their defaults and the ops return gradients through autograd again."""
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
+    case = CASES['small3']
+    netG, netsD = build_nets(case)
+    batch = make_batch(case)
+    netG.to(gpu)
+    for d in netsD:
+        d.to(gpu)
+    tr = T.condGANTrainer(None, None, 256, False)
+    tr.build(netG, netsD)
+    b = to_dev(batch, gpu)
+    tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], b['noise'], b['eps'])
+    assert ops.DIRECT_PARAM_GRAD is False and ops.WGRAD_SIDE_STREAM is False
+    # the facade refuses to step once torch's zero_grad has detached the flat views
+    netsD[0].zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        tr.optimizersD[0].step()
+    tr.optimizersD[0].zero_grad()
+    tr.optimizersD[0].step()
