@@ -84,12 +84,15 @@ def _g_only_backward_check(netG, ostate_g, ds, batch, dims, gpu, what):
     torch.autograd.backward(list(fakes) + [mu, logvar],
                             [d.to(gpu) for d in dfakes] + [dmu.to(gpu), dlv.to(gpu)])
     torch.cuda.synchronize()
-    worst = 0.0
+    worst, worst_k = 0.0, ""
     named = dict(netG.named_parameters())
     for k, g in grads_o.items():
-        worst = max(worst, assert_close_scaled(named[k].grad, g, what="%s dG/%s" % (what, k)))
-    worst = max(worst, assert_close_scaled(emb.grad, gemb_o, what=what + " grad_emb"))
-    print("%s: worst element-wise deviation of a G gradient = %.2e of the tensor's max" % (what, worst))
+        dev_k = assert_close_scaled(named[k].grad, g, what="%s dG/%s" % (what, k))
+        if dev_k > worst:
+            worst, worst_k = dev_k, k
+    dev_e = assert_close_scaled(emb.grad, gemb_o, what=what + " grad_emb")
+    print("%s: worst element-wise deviation of a G gradient = %.2e of the tensor's max (%s); grad_emb %.2e"
+          % (what, worst, worst_k, dev_e))
 
 
 def test_generator_backward_elementwise_from_identical_image_gradients(gpu):
@@ -199,14 +202,18 @@ def test_non_initial_operating_point(gpu):
     (G-only element-wise, D-only with replayed decisions) at that operating point."""
     from oracle import stackgan_oracle as orc
     from speech_to_image_translation_without_text_amd import trainer as T
+    from speech_to_image_translation_without_text_amd.miscc.config import cfg
     case = dict(CASES['small3'], B=8)
     netG, netsD = build_nets(case)
     batch = make_batch(case)
     netG.to(gpu)
     for d in netsD:
         d.to(gpu)
+    LR_D = 2e-3   # ten times the configured rate: the discriminators saturate within tens of iterations
+    cfg.TRAIN.DISCRIMINATOR_LR = LR_D
     tr = T.condGANTrainer(None, None, 256, False)
     tr.build(netG, netsD)
+    cfg.TRAIN.DISCRIMINATOR_LR = 2e-4
     b = to_dev(batch, gpu)
     g = torch.Generator(device=gpu).manual_seed(1234)
     hist = []
@@ -234,9 +241,11 @@ def test_non_initial_operating_point(gpu):
     # segmented gradient checks at this operating point, before either side moves
     sd_snap = [{k: v.clone() for k, v in d.items()} for d in ostate.ds]
     g_snap = {k: v.clone() for k, v in ostate.g.items()}
-    oout = orc.train_step(ostate, obatch, oracle_dims(case))
+    oout = orc.train_step(ostate, obatch, oracle_dims(case), lr_d=LR_D)
     out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], noise, eps)
     torch.cuda.synchronize()
+    print("iteration 61: HIP (errD, errG, kl) = %s, oracle = %s" % ([round(float(o), 5) for o in out],
+                                                                     [round(oout[k], 5) for k in ('errD_total', 'errG_total', 'kl')]))
     for i in range(3):
         assert_close(tr.fake_imgs[i], oout['fake'][i], rtol=1e-3, atol=2e-4, what="img%d after 60 its" % i)
     assert_close(float(out[0]), oout['errD_total'], rtol=2e-3, atol=1e-4, what="errD_total")
@@ -463,9 +472,11 @@ def test_ragged_batch_full_train_step(gpu, B):
     assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total B=%d" % B)
     assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total B=%d" % B)
     assert_close_l2(emb.grad, oout['grad_emb'], 6e-2, what="grad_emb B=%d" % B)
+    # end to end (through discriminators that each side updated itself: first-step Adam moves weights by lr * sign(g),
+    # test_model_gpu.py): norm-wise, as for grad_emb; the element-wise bound is held by the segmented tests above
     named = dict(netG.named_parameters())
     for k, g in oout['grad_g'].items():
-        assert_close_l2(named[k].grad.cpu(), g, 2e-2, what="dG/%s B=%d" % (k, B))
+        assert_close_l2(named[k].grad.cpu(), g, 6e-2, what="dG/%s B=%d" % (k, B))
 
 
 def test_step_scopes_the_direct_gradient_switches(gpu):
