@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     ap.add_argument("--no-side-leg", action="store_true", help="skip the extra bf16x3 measurement of f32 runs (profiling)")
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16"],
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16", "bf16p"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
                          "bf16 planes on the bf16 MFMA (DESIGN.md section 9); f32 runs also report bf16x3 beside the value")
     return ap.parse_args()
@@ -174,7 +174,8 @@ def main():
 
     from speech_to_image_translation_without_text_amd import model, ops, trainer as T
     from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
-    ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 1}[args.math]
+    ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 0, "bf16p": 1}[args.math]
+    ops.ACT_BF16 = args.math == "bf16"
     if args.roofline_only:
         print(json.dumps({"roofline": dominant_kernel_roofline(dev, args.batch, args.math)}))
         return

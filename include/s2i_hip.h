@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S2I_ABI_VERSION 1
+#define S2I_ABI_VERSION 2
 
 /* conv geometry kinds */
 #define S2I_CONV_K1      0  /* 1x1 / nn.Linear (model.py:179, 217)                              */
@@ -45,6 +45,10 @@ extern "C" {
 #define S2I_ACT_LRELU    2  /* nn.LeakyReLU(0.2), model.py:363, 373 */
 #define S2I_ACT_TANH     3  /* model.py:293 */
 #define S2I_ACT_RELU     4  /* speech_encoder.py:12 */
+
+/* element types of activation tensors (bf16 activation mode, BASELINE config 4) */
+#define S2I_DT_F32       0
+#define S2I_DT_BF16      1
 
 /* weight pack modes */
 #define S2I_PACK_PLAIN   0  /* P[t][i][o] = W[o][i][t]                                          */
@@ -158,6 +162,51 @@ int s2i_conv_wgrad_split(const s2i_wgrad_desc* d, int planes, const float* a, co
 int s2i_split_packed_weight(const float* packed, int T, int R, int C, int planes, unsigned short* out_rc,
                             unsigned short* out_cr, void* stream);
 
+
+/* ---- bf16 activation mode (BASELINE config 4: bf16 activations / weights in HBM, bf16 MFMA, fp32 accumulate) -------
+ * Activations between the fused blocks are bf16 NHWC; BatchNorm statistics come from the fp32 accumulators; master
+ * weights, gradients, Adam and EMA stay fp32 (trainer.py:236-252).  The same convolutions as above
+ * (model.py:125-140, 358-398 and their gradients) for layers whose channel count is a multiple of 32:
+ *   - the block stages a 2-D input patch with its halo in LDS once per channel chunk and all taps read from it;
+ *   - weights arrive pre-arranged by s2i_pack_conv_weight_bf16 as Wb[phase][chunk][tap][Npad][CK] bf16, from the packed
+ *     fp32 copy P[t][R][C]: d->wmode = 0 uses P[t][k][n] (forward), 1 uses P[t][n][k] (input gradient), d->flip /
+ *     the transposed-conv parity select the source tap; P may point at a row offset inside a tap (channel split).
+ * d->Cc must be 0 (a broadcast vector is concatenated by the caller), d->act NONE, N and ldy multiples of 8. */
+int    s2i_conv_bf16_eligible(const s2i_conv_desc* d);
+size_t s2i_conv_bf16_workspace_bytes(const s2i_conv_desc* d);
+int    s2i_conv_bf16_stat_parts(const s2i_conv_desc* d);
+size_t s2i_conv_bf16_weight_elems(const s2i_conv_desc* d);
+int s2i_pack_conv_weight_bf16(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
+                              void* stream);
+int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned short* x, const unsigned short* w,
+                          const float* cls_bias, unsigned short* y, float* part, void* ws, size_t ws_bytes,
+                          void* stream);
+/* The fp32-MFMA convolution / weight gradient of s2i_conv_forward_cls / s2i_conv_wgrad with x / y (a / g) stored as
+   S2I_DT_F32 or S2I_DT_BF16: the edges of the bf16 mode (image tensors, channel counts that are not multiples of 32).
+   Two bf16 operands of a weight gradient run on the bf16 matrix cores. */
+int s2i_conv_forward_dt(const s2i_conv_desc* d, const void* x, int x_dtype, const float* cvec, const float* w,
+                        const float* bias, const float* cls_bias, void* y, int y_dtype, float* part, void* ws,
+                        size_t ws_bytes, void* stream);
+size_t s2i_wgrad_workspace_bytes_dt(const s2i_wgrad_desc* d, int a_dtype, int g_dtype);
+int s2i_conv_wgrad_dt(const s2i_wgrad_desc* d, const void* a, int a_dtype, const float* cvec, const void* g,
+                      int g_dtype, float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+/* `_dt` forms of the BatchNorm / activation / layout kernels below: every activation tensor of the call has `dtype` */
+int s2i_bn_act_forward_dt(int dtype, const void* y, long long M, int groups, int C, const float* coef4, int act,
+                          const void* residual, void* out, void* stream);
+int s2i_bn_act_bwd_reduce_dt(int dtype, const void* y, const void* dout, int lddout, long long M, int groups, int C,
+                             const float* coef4, int act, float* part, int nparts, void* stream);
+int s2i_bn_act_bwd_apply_dt(int dtype, const void* y, const void* dout, int lddout, long long M, int groups, int C,
+                            const float* coef4, const float* red2, int act, void* dy, void* stream);
+int s2i_act_backward_dt(int dtype, const void* out, const void* dout, int lddout, long long M, int C, int act,
+                        void* dy, void* stream);
+int s2i_nchw_to_nhwc_dt(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp, void* stream);
+int s2i_nhwc_to_nchw_dt(int dtype, const void* src, int lds, float* dst, int B, int C, int H, int W, void* stream);
+int s2i_spatial_sum_dt(int dtype, const void* src, int ld, int B, int HW, int C, float* dst, void* ws,
+                       size_t ws_bytes, void* stream);
+int s2i_tap_sums_dt(int dtype, const void* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,
+                    void* stream);
+/* dst[n] = (dst_dtype) src[n] for a contiguous tensor, n % 4 == 0 */
+int s2i_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream);
 
 /* OIHW parameter -> packed P[t][Ip][Op] (Ip >= I, Op = O rounded up to 4; padding zero filled) */
 int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, int I, int KH, int KW,

@@ -16,6 +16,8 @@ LIB_PATH = os.path.join(_HERE, "libs2i_hip.so")
 CONV_K1, CONV_K3S1, CONV_K4S2, TCONV_K4S2, CONV_1D = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
 PACK_PLAIN, PACK_UPFOLD = 0, 1
+DT_F32, DT_BF16 = 0, 1
+ABI_VERSION = 2
 
 c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_longlong)
@@ -50,6 +52,24 @@ _SIGNATURES = {
     "s2i_split_packed_weight": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),
     "s2i_wgrad_workspace_bytes_split": (c_size_t, [ctypes.POINTER(WgradDesc), c_int]),
     "s2i_conv_wgrad_split": (c_int, [ctypes.POINTER(WgradDesc), c_int, P, P, P, P, P, c_size_t, P]),
+    "s2i_conv_bf16_eligible": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "s2i_conv_bf16_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "s2i_conv_bf16_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "s2i_conv_bf16_weight_elems": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "s2i_pack_conv_weight_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, c_int, P, P]),
+    "s2i_conv_forward_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
+    "s2i_conv_forward_dt": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),
+    "s2i_wgrad_workspace_bytes_dt": (c_size_t, [ctypes.POINTER(WgradDesc), c_int, c_int]),
+    "s2i_conv_wgrad_dt": (c_int, [ctypes.POINTER(WgradDesc), P, c_int, P, P, c_int, P, P, c_size_t, P]),
+    "s2i_bn_act_forward_dt": (c_int, [c_int, P, c_ll, c_int, c_int, P, c_int, P, P, P]),
+    "s2i_bn_act_bwd_reduce_dt": (c_int, [c_int, P, P, c_int, c_ll, c_int, c_int, P, c_int, P, c_int, P]),
+    "s2i_bn_act_bwd_apply_dt": (c_int, [c_int, P, P, c_int, c_ll, c_int, c_int, P, P, c_int, P, P]),
+    "s2i_act_backward_dt": (c_int, [c_int, P, P, c_int, c_ll, c_int, c_int, P, P]),
+    "s2i_nchw_to_nhwc_dt": (c_int, [c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "s2i_nhwc_to_nchw_dt": (c_int, [c_int, P, c_int, P, c_int, c_int, c_int, c_int, P]),
+    "s2i_spatial_sum_dt": (c_int, [c_int, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "s2i_tap_sums_dt": (c_int, [c_int, P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "s2i_cast": (c_int, [P, c_int, P, c_int, c_ll, P]),
     "s2i_cvec_bias_table": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
     "s2i_border_sums_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "s2i_tap_sums": (c_int, [P, c_int, c_int, c_int, c_int, P, P, c_size_t, P]),
@@ -121,8 +141,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.s2i_version() != 1:
-        raise S2IError("libs2i_hip.so ABI version %d, expected 1" % lib.s2i_version())
+    if lib.s2i_version() != ABI_VERSION:
+        raise S2IError("libs2i_hip.so ABI version %d, expected %d: rebuild it (make -C csrc)" % (lib.s2i_version(), ABI_VERSION))
     _lib = lib
     return lib
 

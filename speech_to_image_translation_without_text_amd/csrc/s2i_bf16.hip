@@ -1,0 +1,651 @@
+// bf16 activation path (BASELINE config 4): implicit-GEMM convolutions whose activations live in HBM as bf16 NHWC,
+// weights as bf16 (fp32 masters stay in the trainer's flat buffers), products on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation, BatchNorm statistics taken from the fp32 accumulators.
+//
+// What is different from the fp32 / split kernels of s2i_igemm.hip (which gather an im2col chunk per 32-deep K step
+// from global memory, i.e. pull every input pixel through L2 once per tap):
+//   * the block stages a 2-D input PATCH with its halo in LDS once per channel chunk -- the pixels of TB images x
+//     (TH-1)*s+KH rows x (TW-1)*s+KW columns -- and every tap reads its MFMA A-fragments from that patch at a
+//     wave-uniform offset.  Out-of-image halo pixels are zero-filled by the bounds-checked buffer load, so the
+//     matrix loop has no masks at all;
+//   * the K loop runs (channel chunk, tap group) instead of (tap, channel): one LDS stage carries all 9 taps of a
+//     3x3 (8 of the 16 taps of a 4x4, the 4 taps of one transposed-conv phase) for CK channels, 32-36 MFMAs per wave
+//     between two barriers instead of 8;
+//   * weights are pre-arranged at pack time in exactly the order the stages consume them,
+//     Wb[phase][chunk][tap][n][CK] (tap flip / transposition / parity tap selection of the input-gradient forms
+//     already applied), so a stage's B tile is ONE contiguous run of global memory;
+//   * LDS rows are CK*2 bytes (32 / 64 / 128) with the 16-byte segments XOR-swizzled by the row index, so a
+//     ds_read_b128 fragment read is conflict-free without padding;
+//   * bf16 results leave through an LDS transpose and 16-byte row-contiguous stores.
+// Rows of the GEMM are output pixels; a block owns a tile of 128 of them shaped TB x TH x TW (powers of two) chosen
+// from the map size, e.g. 4 x 32 pixels of one image on wide maps, 8 whole 4x4 maps at the discriminators' tails.
+#include "s2i_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define S2I_OOB 0x7ffffff0
+
+enum { KB_K3S1 = 0, KB_K4S2 = 1, KB_TCONV = 2 };
+
+struct ConvBP {
+  const unsigned short* __restrict__ x;
+  const unsigned short* __restrict__ w;
+  const float* __restrict__ cls_bias;
+  unsigned short* __restrict__ y;
+  float* __restrict__ part;
+  float* __restrict__ slab;
+  int B, H, W, C;
+  int Ho, Wo;              // output grid of one phase
+  int N, Npad, ldy;
+  int lgTW, lgTH, lgTB;
+  int tilesX, tilesY;      // tiles per image along x / y (powers of two)
+  int PH, PW, npix;
+  int nchunk, splitk, cps;
+  int stats, nparts;
+  long long Mrows;         // rows of y (all phases)
+  unsigned x_bytes, w_bytes;
+};
+
+__device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// KIND: geometry; BN: output channels per block; CK: channels per LDS stage; waves 2x2 (BN >= 64) or 4x1 (BN = 32)
+template <int KIND, int BN, int CK>
+__global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
+  constexpr int T = KIND == KB_K3S1 ? 9 : (KIND == KB_K4S2 ? 16 : 4);
+  constexpr int TG = KIND == KB_K4S2 ? 8 : T;       // taps per LDS stage
+  constexpr int NG = T / TG;
+  constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+  constexpr int TM = 128 / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int SEGS = CK / 8;                      // 16-byte segments per LDS row
+  constexpr int ROWB = CK * 2;
+  constexpr int LGR = SEGS == 2 ? 3 : (SEGS == 4 ? 2 : 1);  // rows per 256-byte bank span = 16 / SEGS -> swizzle shift
+  constexpr int KS = CK / 16;                       // k-steps per tap
+  constexpr int BSEG = TG * BN * SEGS;              // 16-byte segments of one weight stage
+  constexpr int NBL = (BSEG + 255) / 256;
+  constexpr int MAXPIX = KIND == KB_K4S2 ? (CK == 16 ? 800 : 672) : 320;  // plan_bf16 checks the patch against this
+  constexpr int NPL = (MAXPIX * SEGS + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch | weight stage], reused by the epilogue
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + ((p.npix * ROWB + 255) & ~255);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int phase = 0, split = blockIdx.z;
+  if (KIND == KB_TCONV) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  const int py = phase >> 1, px = phase & 1;
+  const int n0 = blockIdx.y * BN;
+  const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
+  const int tix = blockIdx.x & (p.tilesX - 1);
+  const int tiy = (blockIdx.x / p.tilesX) & (p.tilesY - 1);
+  const int tib = blockIdx.x / (p.tilesX * p.tilesY);
+  const int b0 = tib << p.lgTB, oy0 = tiy << p.lgTH, ox0 = tix << p.lgTW;
+  const int PW = p.PW, PH = p.PH;
+  // input coordinate of patch pixel (0, 0)
+  int iy0, ix0;
+  if (KIND == KB_K3S1) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+  else if (KIND == KB_K4S2) { iy0 = 2 * oy0 - 1; ix0 = 2 * ox0 - 1; }
+  else { iy0 = oy0 - (py ? 0 : 1); ix0 = ox0 - (px ? 0 : 1); }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // ---- patch staging plan of this thread: global byte offset (chunk 0) and swizzled LDS offset per load ----
+  int pgo[NPL], plo[NPL];
+  const int nseg = p.npix * SEGS;
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    const int e = tid + q * 256;
+    int go = S2I_OOB, lo = -1;
+    if (e < nseg) {
+      const int pix = e / SEGS, seg = e & (SEGS - 1);
+      const int xl = pix % PW;
+      const int rest = pix / PW;
+      const int yl = rest % PH, tb = rest / PH;
+      const int b = b0 + tb, iy = iy0 + yl, ix = ix0 + xl;
+      if (b < p.B && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) go = (((b * p.H + iy) * p.W + ix) * p.C + seg * 8) * 2;
+      const int xs = KIND == KB_K4S2 ? (xl & 1) * (PW >> 1) + (xl >> 1) : xl;   // even / odd columns de-interleaved
+      const int prow = (tb * PH + yl) * PW + xs;
+      lo = prow * ROWB + ((seg ^ ((prow >> LGR) & (SEGS - 1))) << 4);
+    }
+    pgo[q] = go;
+    plo[q] = lo;
+  }
+  // ---- A fragment rows of this lane: patch row of (tile row, tap (0,0)) ----
+  int arow[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * TM * 32 + i * 32 + l31;
+    const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
+    arow[i] = (tb * PH + (KIND == KB_K4S2 ? 2 * ty : ty)) * PW + tx;
+  }
+  // weight stage: segment e -> (tap, n, seg); global element offset inside the stage and swizzled LDS offset
+  // (computed on the fly: BN and SEGS are powers of two)
+  const int wstage = TG * p.Npad * CK;               // elements per (chunk, tap group)
+  u32x4 ra[NPL], rb[NBL];
+
+  auto fetch = [&](int st, bool with_a) {            // st = chunk * NG + group
+    const int cc = st / NG, tg = st - cc * NG;
+    if (with_a) {
+      const int coff = cc * CK * 2;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) ra[q] = bload16(rx, pgo[q] == S2I_OOB ? S2I_OOB : pgo[q] + coff);
+    }
+    const int wbase = ((phase * p.nchunk + cc) * NG + tg) * wstage + n0 * CK;
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) {
+      const int e = tid + q * 256;
+      const int seg = e & (SEGS - 1), n = (e / SEGS) & (BN - 1), t = e / (SEGS * BN);
+      rb[q] = bload16(rw, e < BSEG ? (wbase + (t * p.Npad + n) * CK + seg * 8) * 2 : S2I_OOB);
+    }
+  };
+  auto stage = [&](bool with_a) {
+    if (with_a) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q)
+        if (plo[q] >= 0) *reinterpret_cast<u32x4*>(As + plo[q]) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) {
+      const int e = tid + q * 256;
+      if (e < BSEG) {
+        const int seg = e & (SEGS - 1), row = e / SEGS;  // row = t * BN + n
+        *reinterpret_cast<u32x4*>(Bs + row * ROWB + ((seg ^ ((row >> LGR) & (SEGS - 1))) << 4)) = rb[q];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunk, c_begin + p.cps);
+  const int s_begin = c_begin * NG, s_end = c_end * NG;
+  if (s_begin < s_end) fetch(s_begin, true);
+  for (int st = s_begin; st < s_end; ++st) {
+    const bool new_a = (st % NG) == 0;
+    stage(new_a);
+    __syncthreads();
+    if (st + 1 < s_end) fetch(st + 1, ((st + 1) % NG) == 0);
+    const int tg = st % NG;
+    // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (two named register sets,
+    // order pinned): the LDS latency hides behind this wave's own MFMAs, and no more than two sets are ever live
+    auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+      const int tl = stp / KS, ks = stp % KS;
+      const int t = tg * TG + tl;
+      int toff;  // patch rows between tap (0,0) and tap t
+      if (KIND == KB_K3S1) { toff = (t / 3) * PW + (t % 3); }
+      else if (KIND == KB_K4S2) { const int dy = t >> 2, dx = t & 3; toff = dy * PW + (dx & 1) * (PW >> 1) + (dx >> 1); }
+      else { const int ta = t >> 1, tb2 = t & 1; toff = (py ? ta : 1 - ta) * PW + (px ? tb2 : 1 - tb2); }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int prow = arow[i] + toff;
+        a[i] = *reinterpret_cast<const bf16x8*>(As + prow * ROWB + (((ks * 2 + lh) ^ ((prow >> LGR) & (SEGS - 1))) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int brow = tl * BN + wn * TN * 32 + j * 32 + l31;
+        b[j] = *reinterpret_cast<const bf16x8*>(Bs + brow * ROWB + (((ks * 2 + lh) ^ ((brow >> LGR) & (SEGS - 1))) << 4));
+      }
+    };
+    auto mma = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NS = TG * KS;
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+    ldfr(0, a0, b0);
+#pragma unroll
+    for (int s2 = 0; s2 < NS; s2 += 2) {
+      if (s2 + 1 < NS) ldfr(s2 + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s2 + 1 < NS) mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  const bool raw = p.splitk > 1;
+  // global row (pixel of y) of tile row r, or -1 beyond the batch
+  auto out_row = [&](int r) -> long long {
+    const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
+    const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
+    if (b >= p.B) return -1;
+    if (KIND == KB_TCONV) return ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+    return ((long long)b * p.Ho + oy) * p.Wo + ox;
+  };
+  if (p.cls_bias && !raw) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int tx = rr & (TW - 1), ty = (rr >> p.lgTW) & (TH - 1), tb = rr >> (p.lgTW + p.lgTH);
+        const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
+        if (b >= p.B) continue;
+        const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+        const float* bp = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) acc[i][j][r] += bp[n];
+        }
+      }
+  }
+  if (raw) {
+    float* outp = p.slab + (size_t)split * p.Mrows * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = out_row(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+        if (row < 0) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) outp[row * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  // bf16 tile through LDS: lanes l and l^1 (columns c, c+1) exchange one register of each row pair so that every lane
+  // owns two adjacent columns of ONE row and writes them as a dword; rows leave as 16-byte row-contiguous stores
+  constexpr int ERS = BN * 2 + 16;
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float mine0 = acc[i][j][2 * q], mine1 = acc[i][j][2 * q + 1];
+        const float give = odd ? mine0 : mine1;
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+        const int reg = 2 * q + (odd ? 1 : 0);
+        const int rr = wm * TM * 32 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        const int col = wn * TN * 32 + j * 32 + (l31 & ~1);
+        const unsigned v = odd ? pack2(got, mine1) : pack2(mine0, got);
+        *reinterpret_cast<unsigned*>(smem + rr * ERS + col * 2) = v;
+      }
+  __syncthreads();
+  {
+    constexpr int SPR = BN / 8;                       // 16-byte segments per row
+#pragma unroll
+    for (int q = 0; q < 128 * SPR / 256; ++q) {
+      const int e = tid + q * 256;
+      const int rr = e / SPR, sg = e & (SPR - 1);
+      const long long row = out_row(rr);
+      const int n = n0 + sg * 8;
+      if (row >= 0 && n < p.N)
+        *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
+    }
+  }
+  if (p.stats) {
+    // column sums of the fp32 accumulators over this block's valid rows (rows beyond the batch gathered zeros)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          sv += v;
+          sq += v * v;
+        }
+      sv += __shfl_xor(sv, 32);
+      sq += __shfl_xor(sq, 32);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + j * 32 + l31;
+        red[(0 * WAVES_M + wm) * BN + col] = sv;
+        red[(1 * WAVES_M + wm) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.N) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES_M; ++q) {
+          sv += red[(0 * WAVES_M + q) * BN + tid];
+          sq += red[(1 * WAVES_M + q) * BN + tid];
+        }
+        const int gm = phase * gridDim.x + blockIdx.x;
+        p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
+        p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
+      }
+    }
+  }
+}
+
+// ---- weights: packed fp32 P[Tsrc][R][C] -> bf16 Wb[phase][chunk][tap][Npad][CK] -------------------------------------
+//   transpose = 0 (forward): n = column of P (cout), k = row of P (cin)
+//   transpose = 1 (input gradient): n = row of P (cin), k = column of P (cout)
+// One thread per 16-byte output segment; for transpose = 0 the 8 values of a segment are a column walk of P, so a
+// 32 x 32 tile goes through LDS (reads coalesced along the columns of P, writes along k).
+__device__ __forceinline__ int src_tap(int kind, int flip, int T, int t, int phase) {
+  if (kind == KB_TCONV) {
+    const int py = phase >> 1, px = phase & 1, a = t >> 1, b = t & 1;
+    const int k4y = py ? (a ? 0 : 2) : (a ? 3 : 1);
+    const int k4x = px ? (b ? 0 : 2) : (b ? 3 : 1);
+    return k4y * 4 + k4x;
+  }
+  return flip ? (T - 1 - t) : t;
+}
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ P, unsigned short* __restrict__ out, int R,
+                                                        int C, int kind, int flip, int transpose, int T, int nphase,
+                                                        int Nn, int Npad, int Kk, int CK) {
+  __shared__ float tile[32][33];
+  const int zt = blockIdx.z;               // phase * T + t
+  const int phase = zt / T, t = zt - phase * T;
+  const int ts = src_tap(kind, flip, T, t, phase);
+  const float* sp = P + (size_t)ts * R * C;
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  // tile[kl][nl]
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = 0.f;
+    if (!transpose) {
+      const int k = k0 + ty + 8 * q, n = n0 + tx;      // P[k][n], coalesced along n
+      if (k < Kk && n < Nn) v = sp[(size_t)k * C + n];
+      tile[ty + 8 * q][tx] = v;
+    } else {
+      const int n = n0 + ty + 8 * q, k = k0 + tx;      // P[n][k], coalesced along k
+      if (k < Kk && n < Nn) v = sp[(size_t)n * C + k];
+      tile[tx][ty + 8 * q] = v;
+    }
+  }
+  __syncthreads();
+  // 32 n x 4 segments of 8 k
+  if (threadIdx.x < 128) {
+    const int nl = threadIdx.x >> 2, sg = threadIdx.x & 3;
+    const int n = n0 + nl, k = k0 + sg * 8;
+    if (n < Npad && k < Kk) {
+      const int nchunk = Kk / CK;
+      const int cc = k / CK, kc = k - cc * CK;
+      u32x4 v;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        f32x2 f = {tile[sg * 8 + 2 * h][nl], tile[sg * 8 + 2 * h + 1][nl]};
+        v[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+      }
+      const size_t o = ((((size_t)phase * nchunk + cc) * T + t) * Npad + n) * CK + kc;
+      *reinterpret_cast<u32x4*>(out + o) = v;
+    }
+  }
+}
+
+// ---- split-K reduction with bf16 output (+ BatchNorm column statistics), as splitk_reduce_stats_kernel -----------------
+__global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __restrict__ slab, int S, long long rows,
+                                                                 int N, unsigned short* __restrict__ y, int ldy,
+                                                                 float* __restrict__ part, int nparts, int cpb, int ppg,
+                                                                 long long Rg) {
+  __shared__ f32x4 sh[2][256];
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.y * cpb + ql;
+  const int Q = N / 4;
+  const int grp = blockIdx.x / ppg, pp = blockIdx.x - grp * ppg;
+  const long long chunk = (Rg + ppg - 1) / ppg;
+  const long long r0 = grp * Rg + pp * chunk;
+  const long long gend = (grp + 1) * Rg < rows ? (grp + 1) * Rg : rows;
+  const long long r1 = r0 + chunk < gend ? r0 + chunk : gend;
+  const size_t sstride = (size_t)rows * N;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  if (quad < Q) {
+    for (long long row = r0 + rl; row < r1; row += rpb) {
+      const float* sp = slab + row * N + quad * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+      for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(sp + s * sstride);
+      u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+      *reinterpret_cast<u32x2*>(y + row * ldy + quad * 4) = o;
+      s0 += v;
+      s1 += v * v;
+    }
+  }
+  if (!part) return;
+  sh[0][tid] = s0;
+  sh[1][tid] = s1;
+  __syncthreads();
+  if (rl == 0 && quad < Q) {
+    for (int r = 1; r < rpb; ++r) {
+      s0 += sh[0][r * cpb + ql];
+      s1 += sh[1][r * cpb + ql];
+    }
+    *reinterpret_cast<f32x4*>(part + ((size_t)0 * nparts + blockIdx.x) * N + quad * 4) = s0;
+    *reinterpret_cast<f32x4*>(part + ((size_t)1 * nparts + blockIdx.x) * N + quad * 4) = s1;
+  }
+}
+
+// ---- host-side planning ------------------------------------------------------------------------------------------
+struct BPlan {
+  int kb, T, NG, Ho, Wo, nphases, BN, CK, Npad;
+  int lgTW, lgTH, lgTB, tilesX, tilesY, tilesB, PH, PW, npix;
+  int nchunk, splitk, cps, gridM, gridN;
+  long long Mrows;
+};
+
+int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
+  S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "conv(bf16): non-positive extent");
+  S2I_REQUIRE(d->Cc == 0, "conv(bf16): broadcast vectors are concatenated by the caller");
+  S2I_REQUIRE(s2i_is_pow2(d->H) && s2i_is_pow2(d->W), "conv(bf16): spatial extents must be powers of two");
+  S2I_REQUIRE(d->Cx >= 32 && (d->Cx % 32) == 0, "conv(bf16): input channels must be a multiple of 32 (Cx=%d)", d->Cx);
+  S2I_REQUIRE((d->N % 8) == 0 && (d->ldy % 8) == 0 && d->ldy >= d->N, "conv(bf16): N and ldy must be multiples of 8");
+  S2I_REQUIRE(d->act == S2I_ACT_NONE, "conv(bf16): no activation epilogue");
+  pl->nphases = 1;
+  switch (d->kind) {
+    case S2I_CONV_K3S1: pl->kb = KB_K3S1; pl->T = 9; pl->NG = 1; pl->Ho = d->H; pl->Wo = d->W; break;
+    case S2I_CONV_K4S2:
+      S2I_REQUIRE(d->H >= 2 && d->W >= 2, "conv(bf16) k4s2: extent < 2");
+      pl->kb = KB_K4S2; pl->T = 16; pl->NG = 2; pl->Ho = d->H / 2; pl->Wo = d->W / 2; break;
+    case S2I_TCONV_K4S2: pl->kb = KB_TCONV; pl->T = 4; pl->NG = 1; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
+    default: S2I_FAIL("conv(bf16): unsupported kind %d", d->kind);
+  }
+  pl->BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
+  int ck = (pl->kb == KB_TCONV ? 4096 : 2048) / pl->BN;
+  if (ck > (pl->kb == KB_K4S2 ? 32 : 64)) ck = pl->kb == KB_K4S2 ? 32 : 64;  // the stride-2 patch is 5 pixels per output pixel
+  while (ck > 16 && (d->Cx % ck) != 0) ck >>= 1;
+  if (pl->BN == 32 && ck < 32) ck = 32;
+  S2I_REQUIRE((d->Cx % ck) == 0, "conv(bf16): %d channels do not split into chunks of %d", d->Cx, ck);
+  pl->CK = ck;
+  pl->Npad = s2i_cdiv(d->N, pl->BN) * pl->BN;
+  // tile of 128 output pixels: as wide as the map allows (up to 32), then rows, then images
+  int tw = pl->Wo < 32 ? pl->Wo : 32;
+  int th = 128 / tw;
+  if (th > pl->Ho) th = pl->Ho;
+  int tb = 128 / (tw * th);
+  pl->lgTW = s2i_ilog2(tw); pl->lgTH = s2i_ilog2(th); pl->lgTB = s2i_ilog2(tb);
+  pl->tilesX = pl->Wo / tw; pl->tilesY = pl->Ho / th; pl->tilesB = s2i_cdiv(d->B, tb);
+  if (pl->kb == KB_K3S1) { pl->PH = th + 2; pl->PW = tw + 2; }
+  else if (pl->kb == KB_K4S2) { pl->PH = 2 * th + 2; pl->PW = 2 * tw + 2; }
+  else { pl->PH = th + 1; pl->PW = tw + 1; }
+  pl->npix = tb * pl->PH * pl->PW;
+  S2I_REQUIRE(pl->npix <= (pl->kb == KB_K4S2 ? (ck == 16 ? 800 : 672) : 320),
+              "conv(bf16): patch of %d pixels exceeds the LDS plan", pl->npix);
+  pl->gridM = pl->tilesX * pl->tilesY * pl->tilesB;
+  pl->gridN = pl->Npad / pl->BN;
+  pl->nchunk = d->Cx / ck;
+  const long long M = (long long)d->B * pl->Ho * pl->Wo;
+  pl->Mrows = M * pl->nphases;
+  S2I_REQUIRE(pl->Mrows * d->ldy < (1ll << 31), "conv(bf16): output too large");
+  if (d->stats && d->groups > 1) {
+    S2I_REQUIRE(pl->kb != KB_TCONV && (d->B % d->groups) == 0 && ((d->B / d->groups) % tb) == 0,
+                "conv(bf16): a tile of %d images straddles the %d BatchNorm groups of batch %d", tb, d->groups, d->B);
+  }
+  const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
+  int splitk = 1;
+  if (blocks < 384 && pl->nchunk >= 4 && !d->nosplit) {
+    splitk = (int)(512 / blocks);
+    if (splitk > pl->nchunk / 2) splitk = pl->nchunk / 2;
+    if (splitk > 32) splitk = 32;
+    if (splitk < 1) splitk = 1;
+  }
+  pl->cps = s2i_cdiv(pl->nchunk, splitk);
+  pl->splitk = s2i_cdiv(pl->nchunk, pl->cps);
+  return 0;
+}
+
+int bf16_stat_parts(const BPlan& pl, int groups) {
+  if (groups < 1) groups = 1;
+  if (pl.splitk > 1) {
+    int ppg = s2i_cdiv(pl.Mrows / groups, 8);
+    if (ppg > 512 / groups) ppg = 512 / groups;
+    if (ppg < 1) ppg = 1;
+    return ppg * groups;
+  }
+  return pl.gridM * pl.nphases;
+}
+
+size_t bf16_smem_bytes(const BPlan& pl) {
+  const int rowb = pl.CK * 2, tg = pl.kb == KB_K4S2 ? 8 : pl.T;
+  const size_t ab = ((size_t)pl.npix * rowb + 255) & ~(size_t)255;
+  const size_t main_b = ab + (size_t)tg * pl.BN * rowb;
+  const size_t epi = (size_t)128 * (pl.BN * 2 + 16);
+  return main_b > epi ? main_b : epi;
+}
+
+bool bf16_has_kernel(int kb, int bn, int ck) {
+  if (kb == KB_TCONV) return (bn == 128 && ck == 32) || (bn == 64 && ck == 64) || (bn == 32 && (ck == 64 || ck == 32));
+  if (kb == KB_K4S2) return (bn == 128 && ck == 16) || (bn == 64 && ck == 32) || (bn == 32 && ck == 32);
+  return (bn == 128 && ck == 16) || (bn == 64 && ck == 32) || (bn == 32 && (ck == 64 || ck == 32));
+}
+
+template <int KIND, int BN, int CK>
+int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
+  const size_t shb = bf16_smem_bytes(pl);
+  static bool raised = false;  // > 64 KB of dynamic LDS needs the attribute once per kernel
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<KIND, BN, CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       96 * 1024);
+    if (e != hipSuccess) S2I_FAIL("conv(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_kernel<KIND, BN, CK>), grid, dim3(256), shb, st, p);
+  return 0;
+}
+
+int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
+  const int kb = pl.kb, bn = pl.BN, ck = pl.CK;
+#define S2I_CASE(K, bn_, ck_) if (kb == K && bn == bn_ && ck == ck_) return launch_one<K, bn_, ck_>(pl, p, grid, st);
+  S2I_CASE(KB_K3S1, 128, 16) S2I_CASE(KB_K3S1, 64, 32) S2I_CASE(KB_K3S1, 32, 64) S2I_CASE(KB_K3S1, 32, 32)
+  S2I_CASE(KB_K4S2, 128, 16) S2I_CASE(KB_K4S2, 64, 32) S2I_CASE(KB_K4S2, 32, 32)
+  S2I_CASE(KB_TCONV, 128, 32) S2I_CASE(KB_TCONV, 64, 64) S2I_CASE(KB_TCONV, 32, 64) S2I_CASE(KB_TCONV, 32, 32)
+#undef S2I_CASE
+  S2I_FAIL("conv(bf16): no kernel for kind %d BN=%d CK=%d", kb, bn, ck);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int s2i_conv_bf16_eligible(const s2i_conv_desc* d) {
+  BPlan pl;
+  const int rc = plan_bf16(d, &pl);
+  if (rc) return 0;
+  return bf16_has_kernel(pl.kb, pl.BN, pl.CK) ? 1 : 0;
+}
+
+extern "C" size_t s2i_conv_bf16_workspace_bytes(const s2i_conv_desc* d) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return 0;
+  return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
+}
+
+extern "C" int s2i_conv_bf16_stat_parts(const s2i_conv_desc* d) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return -1;
+  return bf16_stat_parts(pl, d->groups);
+}
+
+extern "C" size_t s2i_conv_bf16_weight_elems(const s2i_conv_desc* d) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return 0;
+  return (size_t)pl.nphases * pl.T * pl.Npad * d->Cx;
+}
+
+extern "C" int s2i_pack_conv_weight_bf16(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
+                                         void* stream) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return 1;
+  S2I_REQUIRE(packed && out, "pack(bf16): null pointer");
+  const int transpose = d->wmode != 0;
+  const int Kk = d->Cx, Nn = d->N;
+  if (transpose) S2I_REQUIRE(R >= Nn && C >= Kk, "pack(bf16): P is %d x %d, need rows >= %d cols >= %d", R, C, Nn, Kk);
+  else S2I_REQUIRE(R >= Kk && C >= Nn, "pack(bf16): P is %d x %d, need rows >= %d cols >= %d", R, C, Kk, Nn);
+  dim3 grid(pl.Npad / 32, Kk / 32, pl.nphases * pl.T);
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST, packed, out, R, C, pl.kb, d->flip, transpose, pl.T,
+                     pl.nphases, Nn, pl.Npad, Kk, pl.CK);
+  S2I_LAUNCH_CHECK("pack_bf16");
+  return 0;
+}
+
+extern "C" int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned short* x, const unsigned short* w,
+                                     const float* cls_bias, unsigned short* y, float* part, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return 1;
+  S2I_REQUIRE(x && w && y, "conv(bf16): null operand");
+  S2I_REQUIRE(!cls_bias || (d->kind == S2I_CONV_K3S1 && pl.splitk == 1), "conv(bf16): class bias needs an unsplit 3x3 conv");
+  S2I_REQUIRE(!d->stats || part, "conv(bf16): stats requested without a partial buffer");
+  const size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
+  S2I_REQUIRE(ws_bytes >= need && (need == 0 || ws), "conv(bf16): workspace too small (%zu < %zu)", ws_bytes, need);
+  ConvBP p;
+  p.x = x; p.w = w; p.cls_bias = cls_bias; p.y = y; p.part = part; p.slab = (float*)ws;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.C = d->Cx; p.Ho = pl.Ho; p.Wo = pl.Wo;
+  p.N = d->N; p.Npad = pl.Npad; p.ldy = d->ldy;
+  p.lgTW = pl.lgTW; p.lgTH = pl.lgTH; p.lgTB = pl.lgTB; p.tilesX = pl.tilesX; p.tilesY = pl.tilesY;
+  p.PH = pl.PH; p.PW = pl.PW; p.npix = pl.npix;
+  p.nchunk = pl.nchunk; p.splitk = pl.splitk; p.cps = pl.cps;
+  p.stats = d->stats; p.nparts = pl.gridM * pl.nphases; p.Mrows = pl.Mrows;
+  const unsigned long long xb = (unsigned long long)d->B * d->H * d->W * d->Cx * 2ull;
+  const unsigned long long wb = (unsigned long long)pl.nphases * pl.T * pl.Npad * d->Cx * 2ull;
+  S2I_REQUIRE(xb < 0x7ff00000ull && wb < 0x7ff00000ull, "conv(bf16): tensor exceeds the 2 GiB buffer-addressing window");
+  p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
+  if (launch_conv_bf16(pl, p, grid, ST)) return 1;
+  S2I_LAUNCH_CHECK("conv_bf16");
+  if (pl.splitk > 1) {
+    S2I_REQUIRE((d->N % 4) == 0, "conv(bf16): split-K needs N %% 4 == 0");
+    const int Q = d->N / 4;
+    int cpb = 1;
+    while (cpb < Q && cpb < 256) cpb <<= 1;
+    const int groups = d->groups < 1 ? 1 : d->groups;
+    const int nparts = bf16_stat_parts(pl, groups);
+    hipLaunchKernelGGL(splitk_reduce_bf16_kernel, dim3(nparts, (Q + cpb - 1) / cpb), dim3(256), 0, ST, (const float*)ws,
+                       pl.splitk, pl.Mrows, d->N, y, d->ldy, d->stats ? part : nullptr, nparts, cpb, nparts / groups,
+                       pl.Mrows / groups);
+    S2I_LAUNCH_CHECK("splitk_reduce_bf16");
+  }
+  return 0;
+}

@@ -11,6 +11,27 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// activation tensors are fp32 or bf16 (bf16 activation mode, BASELINE config 4): T = float | bf16_t; the arithmetic of
+// every kernel below stays fp32, only the HBM representation changes
+struct bf16_t { unsigned short v; };
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+  const u32x2 h = *reinterpret_cast<const u32x2*>(p);
+  return f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+               __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+  const f32x2_ a = {v[0], v[1]}, b = {v[2], v[3]};
+  *reinterpret_cast<u32x2*>(p) = u32x2{__builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2_)),
+                                       __builtin_bit_cast(unsigned, __builtin_convertvector(b, bf16x2_))};
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __builtin_bit_cast(float, (unsigned)p->v << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { p->v = __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 // thread layout for per-channel reductions over the rows of an [M][C] tensor:
 // `cpb` threads across channel quads, 256/cpb row lanes.
 struct RedGeom {
@@ -29,7 +50,8 @@ static RedGeom red_geom(int C) {
 
 // ---- per-quad value functors ------------------------------------------------------------------
 // dz for BN-channel quad `quad` at `row`, un-doing the activation that followed BatchNorm
-__device__ __forceinline__ f32x4 act_dz(const float* __restrict__ y, const float* __restrict__ dout, int lddout,
+template <typename T>
+__device__ __forceinline__ f32x4 act_dz(const T* __restrict__ y, const T* __restrict__ dout, int lddout,
                                         long long row, int C, int quad, const float* __restrict__ coef,
                                         int act, f32x4 yv) {
   const float* scale = coef + 2 * C;
@@ -63,9 +85,9 @@ __device__ __forceinline__ f32x4 act_dz(const float* __restrict__ y, const float
   return dz;
 }
 
-template <int MODE>  // 0: (y, y^2)   1: (dz, dz*xhat)
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ y, int ldy,
-                                                        const float* __restrict__ dout, int lddout,
+template <int MODE, typename T>  // 0: (y, y^2)   1: (dz, dz*xhat)
+__global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y, int ldy,
+                                                        const T* __restrict__ dout, int lddout,
                                                         long long M, int C, const float* __restrict__ coef,
                                                         int act, float* __restrict__ part, int nparts, int cpb,
                                                         int ppg, long long Rg) {
@@ -271,10 +293,11 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
   out[3 * C + c] = beta[c] - rmean[c] * sc;
 }
 
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ y, long long M, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, long long M, int C,
                                                          const float* __restrict__ coef0, int act,
-                                                         const float* __restrict__ residual,
-                                                         float* __restrict__ out, int G, unsigned Rg) {
+                                                         const T* __restrict__ residual,
+                                                         T* __restrict__ out, int G, unsigned Rg) {
   const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
   const int Qo = Cout / 4;
   const long long total = M * Qo;
@@ -307,11 +330,12 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __restrict__ y,
-                                                               const float* __restrict__ dout, int lddout,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ y,
+                                                               const T* __restrict__ dout, int lddout,
                                                                long long M, int C, const float* __restrict__ coef0,
                                                                const float* __restrict__ red20, int act,
-                                                               float* __restrict__ dy, int G, unsigned Rg) {
+                                                               T* __restrict__ dy, int G, unsigned Rg) {
   const int Q = C / 4;
   const long long total = M * Q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -335,9 +359,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const float* __re
   }
 }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ out, const T* __restrict__ dout,
                                                       int lddout, long long M, int C, int act,
-                                                      float* __restrict__ dy) {
+                                                      T* __restrict__ dy) {
   const int Q = C / 4;
   const long long total = M * Q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -385,7 +410,8 @@ __global__ void glu_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 // ---- layout -----------------------------------------------------------------------------------
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW,
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int B, int C, int HW,
                                     int Cp) {
   const long long total = (long long)B * HW * Cp;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -394,7 +420,7 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
     const long long bp = e / Cp;
     const int pix = (int)(bp % HW);
     const int b = (int)(bp / HW);
-    dst[e] = c < C ? src[((long long)b * C + c) * HW + pix] : 0.f;
+    st1(dst + e, c < C ? src[((long long)b * C + c) * HW + pix] : 0.f);
   }
 }
 // image fast path: C = 3 -> Cp = 4, one pixel per thread
@@ -409,7 +435,8 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ src, float* __re
     st4(dst + e * 4, v);
   }
 }
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int B, int C,
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int lds, float* __restrict__ dst, int B, int C,
                                     int HW) {
   const long long total = (long long)B * C * HW;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -418,7 +445,7 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int lds, floa
     const long long bc = e / HW;
     const int c = (int)(bc % C);
     const long long b = bc / C;
-    dst[e] = src[(b * HW + pix) * lds + c];
+    dst[e] = ld1(src + (b * HW + pix) * lds + c);
   }
 }
 
@@ -452,7 +479,8 @@ __global__ void u8_to_image_kernel(const unsigned char* __restrict__ src, float*
 }
 
 // per-image column sums, two stages: [B][S][C] partials then the S-sum
-__global__ __launch_bounds__(256) void spatial_sum_stage1(const float* __restrict__ src, int ld, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_sum_stage1(const T* __restrict__ src, int ld, int HW, int C,
                                                           int S, float* __restrict__ tmp, int cpb) {
   __shared__ f32x4 sh[256];
   const int tid = threadIdx.x;
@@ -523,7 +551,8 @@ __global__ void cvec_bias_table_kernel(const float* __restrict__ taps, int B, in
 
 // stage 1: per image and row band, 9 border sums per channel:
 //   0 total, 1 row y=0, 2 row y=H-1, 3 col x=0, 4 col x=W-1, 5..8 corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
-__global__ __launch_bounds__(256) void border_sums_stage1(const float* __restrict__ dy, int H, int W, int C, int S,
+template <typename T>
+__global__ __launch_bounds__(256) void border_sums_stage1(const T* __restrict__ dy, int H, int W, int C, int S,
                                                           float* __restrict__ tmp, int cpb) {
   __shared__ f32x4 sh[256];
   const int tid = threadIdx.x;
@@ -1005,6 +1034,12 @@ __global__ void scale_dev_kernel(float* __restrict__ y, const float* __restrict_
 }
 __global__ void increment_kernel(int* c) { c[0] += 1; }
 
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n4) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (long long)gridDim.x * blockDim.x)
+    st4(dst + e * 4, ld4(src + e * 4));
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 2048 * 4) {
   long long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -1019,7 +1054,7 @@ inline int grid_for(long long total, int block = 256, int cap = 2048 * 4) {
 extern "C" int s2i_colstats(const float* y, long long M, int C, int ldy, float* part, int nparts, void* stream) {
   S2I_REQUIRE(y && part && M > 0 && C > 0 && C % 4 == 0 && ldy % 4 == 0 && nparts > 0, "colstats: bad args");
   RedGeom g = red_geom(C);
-  hipLaunchKernelGGL((colreduce_kernel<0>), dim3(nparts, g.gy), dim3(256), 0, ST, y, ldy, (const float*)nullptr, 0,
+  hipLaunchKernelGGL((colreduce_kernel<0, float>), dim3(nparts, g.gy), dim3(256), 0, ST, y, ldy, (const float*)nullptr, 0,
                      M, C, (const float*)nullptr, 0, part, nparts, g.cpb, nparts, M);
   S2I_LAUNCH_CHECK("colstats");
   return 0;
@@ -1082,30 +1117,56 @@ extern "C" int s2i_bn_eval_coeffs(int C, const float* gamma, const float* beta, 
   return 0;
 }
 
-extern "C" int s2i_bn_act_forward(const float* y, long long M, int groups, int C, const float* coef4, int act,
-                                  const float* residual, float* out, void* stream) {
+#define S2I_DT_CHECK(dt, name) S2I_REQUIRE((dt) == S2I_DT_F32 || (dt) == S2I_DT_BF16, name ": unknown dtype %d", (dt))
+
+template <typename T>
+static int bn_act_forward_impl(const T* y, long long M, int groups, int C, const float* coef4, int act,
+                               const T* residual, T* out, void* stream) {
   S2I_REQUIRE(y && coef4 && out && M > 0 && C > 0, "bn_act_forward: bad args");
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_forward: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_forward: C=%d not aligned for act %d", C, act);
   S2I_REQUIRE(!(residual && act == S2I_ACT_GLU), "bn_act_forward: residual with GLU unsupported");
   const long long total = M * ((act == S2I_ACT_GLU ? C / 2 : C) / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out,
+  hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out,
                      groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_forward");
   return 0;
 }
+extern "C" int s2i_bn_act_forward(const float* y, long long M, int groups, int C, const float* coef4, int act,
+                                  const float* residual, float* out, void* stream) {
+  return bn_act_forward_impl<float>(y, M, groups, C, coef4, act, residual, out, stream);
+}
+extern "C" int s2i_bn_act_forward_dt(int dtype, const void* y, long long M, int groups, int C, const float* coef4, int act,
+                                     const void* residual, void* out, void* stream) {
+  S2I_DT_CHECK(dtype, "bn_act_forward");
+  if (dtype == S2I_DT_BF16)
+    return bn_act_forward_impl<bf16_t>((const bf16_t*)y, M, groups, C, coef4, act, (const bf16_t*)residual, (bf16_t*)out, stream);
+  return bn_act_forward_impl<float>((const float*)y, M, groups, C, coef4, act, (const float*)residual, (float*)out, stream);
+}
 
-extern "C" int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int groups, int C,
-                                     const float* coef4, int act, float* part, int nparts, void* stream) {
+template <typename T>
+static int bn_act_bwd_reduce_impl(const T* y, const T* dout, int lddout, long long M, int groups, int C,
+                                  const float* coef4, int act, float* part, int nparts, void* stream) {
   S2I_REQUIRE(y && dout && coef4 && part && M > 0 && nparts > 0, "bn_act_bwd_reduce: bad args");
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && nparts % groups == 0, "bn_act_bwd_reduce: bad grouping");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_reduce: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_reduce: lddout alignment");
   RedGeom g = red_geom(C);
-  hipLaunchKernelGGL((colreduce_kernel<1>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
+  hipLaunchKernelGGL((colreduce_kernel<1, T>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
                      act, part, nparts, g.cpb, nparts / groups, M / groups);
   S2I_LAUNCH_CHECK("bn_act_bwd_reduce");
   return 0;
+}
+extern "C" int s2i_bn_act_bwd_reduce(const float* y, const float* dout, int lddout, long long M, int groups, int C,
+                                     const float* coef4, int act, float* part, int nparts, void* stream) {
+  return bn_act_bwd_reduce_impl<float>(y, dout, lddout, M, groups, C, coef4, act, part, nparts, stream);
+}
+extern "C" int s2i_bn_act_bwd_reduce_dt(int dtype, const void* y, const void* dout, int lddout, long long M, int groups,
+                                        int C, const float* coef4, int act, float* part, int nparts, void* stream) {
+  S2I_DT_CHECK(dtype, "bn_act_bwd_reduce");
+  if (dtype == S2I_DT_BF16)
+    return bn_act_bwd_reduce_impl<bf16_t>((const bf16_t*)y, (const bf16_t*)dout, lddout, M, groups, C, coef4, act, part, nparts, stream);
+  return bn_act_bwd_reduce_impl<float>((const float*)y, (const float*)dout, lddout, M, groups, C, coef4, act, part, nparts, stream);
 }
 
 extern "C" int s2i_bn_bwd_finalize(const float* part, int nparts, int groups, int C, long long count, float* dgamma,
@@ -1114,24 +1175,47 @@ extern "C" int s2i_bn_bwd_finalize(const float* part, int nparts, int groups, in
                          dbeta, accumulate, stream);
 }
 
-extern "C" int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int groups, int C,
-                                    const float* coef4, const float* red2, int act, float* dy, void* stream) {
+template <typename T>
+static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long long M, int groups, int C,
+                                 const float* coef4, const float* red2, int act, T* dy, void* stream) {
   S2I_REQUIRE(y && dout && coef4 && red2 && dy && M > 0, "bn_act_bwd_apply: bad args");
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_bwd_apply: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_apply: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_apply: lddout alignment");
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
                      coef4, red2, act, dy, groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_bwd_apply");
   return 0;
 }
+extern "C" int s2i_bn_act_bwd_apply(const float* y, const float* dout, int lddout, long long M, int groups, int C,
+                                    const float* coef4, const float* red2, int act, float* dy, void* stream) {
+  return bn_act_bwd_apply_impl<float>(y, dout, lddout, M, groups, C, coef4, red2, act, dy, stream);
+}
+extern "C" int s2i_bn_act_bwd_apply_dt(int dtype, const void* y, const void* dout, int lddout, long long M, int groups,
+                                       int C, const float* coef4, const float* red2, int act, void* dy, void* stream) {
+  S2I_DT_CHECK(dtype, "bn_act_bwd_apply");
+  if (dtype == S2I_DT_BF16)
+    return bn_act_bwd_apply_impl<bf16_t>((const bf16_t*)y, (const bf16_t*)dout, lddout, M, groups, C, coef4, red2, act, (bf16_t*)dy, stream);
+  return bn_act_bwd_apply_impl<float>((const float*)y, (const float*)dout, lddout, M, groups, C, coef4, red2, act, (float*)dy, stream);
+}
 
-extern "C" int s2i_act_backward(const float* out, const float* dout, int lddout, long long M, int C, int act,
-                                float* dy, void* stream) {
+template <typename T>
+static int act_backward_impl(const T* out, const T* dout, int lddout, long long M, int C, int act, T* dy, void* stream) {
   S2I_REQUIRE(out && dout && dy && M > 0 && C > 0 && C % 4 == 0 && lddout % 4 == 0, "act_backward: bad args");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
+  hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
   S2I_LAUNCH_CHECK("act_backward");
   return 0;
+}
+extern "C" int s2i_act_backward(const float* out, const float* dout, int lddout, long long M, int C, int act,
+                                float* dy, void* stream) {
+  return act_backward_impl<float>(out, dout, lddout, M, C, act, dy, stream);
+}
+extern "C" int s2i_act_backward_dt(int dtype, const void* out, const void* dout, int lddout, long long M, int C, int act,
+                                   void* dy, void* stream) {
+  S2I_DT_CHECK(dtype, "act_backward");
+  if (dtype == S2I_DT_BF16)
+    return act_backward_impl<bf16_t>((const bf16_t*)out, (const bf16_t*)dout, lddout, M, C, act, (bf16_t*)dy, stream);
+  return act_backward_impl<float>((const float*)out, (const float*)dout, lddout, M, C, act, (float*)dy, stream);
 }
 
 extern "C" int s2i_glu_forward(const float* x, long long M, int C, float* out, void* stream) {
@@ -1153,7 +1237,7 @@ extern "C" int s2i_nchw_to_nhwc(const float* src, float* dst, int B, int C, int 
     hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for((long long)B * H * W)), dim3(256), 0, ST, src, dst, B,
                        H * W);
   } else {
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long long)B * H * W * Cp)), dim3(256), 0, ST, src, dst, B,
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for((long long)B * H * W * Cp)), dim3(256), 0, ST, src, dst, B,
                        C, H * W, Cp);
   }
   S2I_LAUNCH_CHECK("nchw_to_nhwc");
@@ -1161,8 +1245,27 @@ extern "C" int s2i_nchw_to_nhwc(const float* src, float* dst, int B, int C, int 
 }
 extern "C" int s2i_nhwc_to_nchw(const float* src, int lds, float* dst, int B, int C, int H, int W, void* stream) {
   S2I_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && lds >= C, "nhwc_to_nchw: bad args");
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, ST, src, lds, dst,
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, ST, src, lds, dst,
                      B, C, H * W);
+  S2I_LAUNCH_CHECK("nhwc_to_nchw");
+  return 0;
+}
+/* the same with the NHWC side stored as bf16 (the NCHW side stays fp32: the module boundary) */
+extern "C" int s2i_nchw_to_nhwc_dt(int dtype, const float* src, void* dst, int B, int C, int H, int W, int Cp, void* stream) {
+  S2I_DT_CHECK(dtype, "nchw_to_nhwc");
+  if (dtype == S2I_DT_F32) return s2i_nchw_to_nhwc(src, (float*)dst, B, C, H, W, Cp, stream);
+  S2I_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && Cp >= C, "nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for((long long)B * H * W * Cp)), dim3(256), 0, ST, src,
+                     (bf16_t*)dst, B, C, H * W, Cp);
+  S2I_LAUNCH_CHECK("nchw_to_nhwc");
+  return 0;
+}
+extern "C" int s2i_nhwc_to_nchw_dt(int dtype, const void* src, int lds, float* dst, int B, int C, int H, int W, void* stream) {
+  S2I_DT_CHECK(dtype, "nhwc_to_nchw");
+  if (dtype == S2I_DT_F32) return s2i_nhwc_to_nchw((const float*)src, lds, dst, B, C, H, W, stream);
+  S2I_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0 && lds >= C, "nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for((long long)B * C * H * W)), dim3(256), 0, ST,
+                     (const bf16_t*)src, lds, dst, B, C, H * W);
   S2I_LAUNCH_CHECK("nhwc_to_nchw");
   return 0;
 }
@@ -1191,18 +1294,29 @@ static int spatial_segments(int HW) {
 extern "C" size_t s2i_spatial_sum_workspace_bytes(int B, int HW, int C) {
   return (size_t)B * spatial_segments(HW) * C * sizeof(float);
 }
-extern "C" int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, float* dst, void* ws, size_t ws_bytes,
-                               void* stream) {
+template <typename T>
+static int spatial_sum_impl(const T* src, int ld, int B, int HW, int C, float* dst, void* ws, size_t ws_bytes,
+                            void* stream) {
   S2I_REQUIRE(src && dst && B > 0 && HW > 0 && C > 0 && C % 4 == 0 && ld % 4 == 0 && ld >= C,
               "spatial_sum: bad args");
   const int S = spatial_segments(HW);
   S2I_REQUIRE(ws && ws_bytes >= (size_t)B * S * C * sizeof(float), "spatial_sum: workspace too small");
   RedGeom g = red_geom(C);
-  hipLaunchKernelGGL(spatial_sum_stage1, dim3(B, S, g.gy), dim3(256), 0, ST, src, ld, HW, C, S, (float*)ws, g.cpb);
+  hipLaunchKernelGGL(spatial_sum_stage1<T>, dim3(B, S, g.gy), dim3(256), 0, ST, src, ld, HW, C, S, (float*)ws, g.cpb);
   S2I_LAUNCH_CHECK("spatial_sum_stage1");
   hipLaunchKernelGGL(spatial_sum_stage2, dim3((B * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, S, C, dst);
   S2I_LAUNCH_CHECK("spatial_sum_stage2");
   return 0;
+}
+extern "C" int s2i_spatial_sum(const float* src, int ld, int B, int HW, int C, float* dst, void* ws, size_t ws_bytes,
+                               void* stream) {
+  return spatial_sum_impl<float>(src, ld, B, HW, C, dst, ws, ws_bytes, stream);
+}
+extern "C" int s2i_spatial_sum_dt(int dtype, const void* src, int ld, int B, int HW, int C, float* dst, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  S2I_DT_CHECK(dtype, "spatial_sum");
+  if (dtype == S2I_DT_BF16) return spatial_sum_impl<bf16_t>((const bf16_t*)src, ld, B, HW, C, dst, ws, ws_bytes, stream);
+  return spatial_sum_impl<float>((const float*)src, ld, B, HW, C, dst, ws, ws_bytes, stream);
 }
 
 extern "C" int s2i_cvec_bias_table(const float* cvec, const float* packed, int B, int Cc, int Ip, int Op, int N,
@@ -1226,17 +1340,40 @@ static int border_segments(int H) {
 extern "C" size_t s2i_border_sums_workspace_bytes(int B, int H, int W, int C) {
   return (size_t)B * border_segments(H) * 9 * C * sizeof(float);
 }
-extern "C" int s2i_tap_sums(const float* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,
-                            void* stream) {
+template <typename T>
+static int tap_sums_impl(const T* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes, void* stream) {
   S2I_REQUIRE(dy && tapsum && B > 0 && H > 1 && W > 1 && C > 0 && C % 4 == 0, "tap_sums: bad args");
   const int S = border_segments(H);
   S2I_REQUIRE(ws && ws_bytes >= (size_t)B * S * 9 * C * sizeof(float), "tap_sums: workspace too small");
   RedGeom g = red_geom(C);
-  hipLaunchKernelGGL(border_sums_stage1, dim3(B, S, g.gy), dim3(256), 0, ST, dy, H, W, C, S, (float*)ws, g.cpb);
+  hipLaunchKernelGGL(border_sums_stage1<T>, dim3(B, S, g.gy), dim3(256), 0, ST, dy, H, W, C, S, (float*)ws, g.cpb);
   S2I_LAUNCH_CHECK("border_sums_stage1");
   hipLaunchKernelGGL(border_sums_stage2, dim3((B * C + 255) / 256), dim3(256), 0, ST, (const float*)ws, B, S, C,
                      tapsum);
   S2I_LAUNCH_CHECK("border_sums_stage2");
+  return 0;
+}
+extern "C" int s2i_tap_sums(const float* dy, int B, int H, int W, int C, float* tapsum, void* ws, size_t ws_bytes,
+                            void* stream) {
+  return tap_sums_impl<float>(dy, B, H, W, C, tapsum, ws, ws_bytes, stream);
+}
+extern "C" int s2i_tap_sums_dt(int dtype, const void* dy, int B, int H, int W, int C, float* tapsum, void* ws,
+                               size_t ws_bytes, void* stream) {
+  S2I_DT_CHECK(dtype, "tap_sums");
+  if (dtype == S2I_DT_BF16) return tap_sums_impl<bf16_t>((const bf16_t*)dy, B, H, W, C, tapsum, ws, ws_bytes, stream);
+  return tap_sums_impl<float>((const float*)dy, B, H, W, C, tapsum, ws, ws_bytes, stream);
+}
+
+/* element type conversion of a contiguous tensor: dst_dtype[n] = src_dtype[n] (n % 4 == 0) */
+extern "C" int s2i_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, void* stream) {
+  S2I_DT_CHECK(src_dtype, "cast");
+  S2I_DT_CHECK(dst_dtype, "cast");
+  S2I_REQUIRE(src && dst && n > 0 && (n % 4) == 0 && src_dtype != dst_dtype, "cast: bad args");
+  if (src_dtype == S2I_DT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid_for(n / 4)), dim3(256), 0, ST, (const float*)src, (bf16_t*)dst, n / 4);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid_for(n / 4)), dim3(256), 0, ST, (const bf16_t*)src, (float*)dst, n / 4);
+  S2I_LAUNCH_CHECK("cast");
   return 0;
 }
 extern "C" int s2i_cvec_grads(const float* cvec, const float* packed, const float* tapsum, int B, int Cc, int Ip, int Op,

@@ -37,6 +37,7 @@ struct IgemmP {
   int ldw, wR, ldy, nparts;
   int g_kw, g_s, g_pad;  // geometry of S2I_CONV_1D (1 x kw taps along W, stride, padding)
   int wt;                // weights read transposed per tap (small_n_conv_kernel; the igemm takes it as a template flag)
+  int x16, y16;          // x / y hold bf16 instead of fp32 (bf16 activation mode: the arithmetic here stays fp32)
   unsigned x_bytes, c_bytes, w_bytes;
   long long Mrows;
   // split-bf16 weights [plane][tap][n][k] (igemm_fwd_split_kernel)
@@ -153,6 +154,16 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) 
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// four consecutive elements at the byte offset an fp32 tensor would have; `is16`: the tensor holds bf16 (half the offset)
+__device__ __forceinline__ f32x4 bload4_any(__amdgpu_buffer_rsrc_t r, int byte_off, int is16) {
+  if (!is16) return bload4(r, byte_off);
+  const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off == S2I_OOB ? S2I_OOB : (byte_off >> 1), 0, 0);
+  return f32x4{__builtin_bit_cast(float, v[0] << 16), __builtin_bit_cast(float, v[0] & 0xffff0000u),
+               __builtin_bit_cast(float, v[1] << 16), __builtin_bit_cast(float, v[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+
 // CA32: gathered channel count (and the broadcast-vector part of it) is a multiple of 32, so a 32-deep K
 // chunk lies inside ONE tap (and entirely in x or entirely in cvec): the tap decode is scalar work.
 // Measured alternatives that lost (MI355X, 64->128 k4s2 on 24x128x128): two LDS stages with one barrier per
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
         const int toff = ((dy * p.W + dx) * p.Cx + (c0 - p.Cc)) * 4;
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i)
-          ra[i] = bload4(rx, ((amask[i] >> t) & 1u) ? aoff[i] + toff : S2I_OOB);
+          ra[i] = bload4_any(rx, ((amask[i] >> t) & 1u) ? aoff[i] + toff : S2I_OOB, p.x16);
       }
       const int wbase = WT ? (tw * p.wR * p.ldw + c0) * 4 : (tw * p.wR + c0) * p.ldw * 4;
 #pragma unroll
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
 #pragma unroll
       for (int i = 0; i < ASLOTS; ++i) {
         const bool ok = kvalid && ((amask[i] >> t) & 1u);
-        f32x4 vx = bload4(rx, (ok && !from_vec) ? aoff[i] + toff : S2I_OOB);
+        f32x4 vx = bload4_any(rx, (ok && !from_vec) ? aoff[i] + toff : S2I_OOB, p.x16);
         if (p.Cc > 0) vx += bload4(rc, (ok && from_vec) ? acoff[i] + (c - kq * 4) * 4 : S2I_OOB);
         ra[i] = vx;
       }
@@ -375,7 +386,8 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
             else if (p.act == S2I_ACT_TANH) v = tanhf(v);
             else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
           }
-          outp[row * ldo + n] = v;
+          if (!raw && p.y16) reinterpret_cast<unsigned short*>(outp)[row * ldo + n] = f2bf(v);
+          else outp[row * ldo + n] = v;
         }
       }
     }
@@ -777,12 +789,20 @@ __global__ __launch_bounds__(256) void small_n_conv_kernel(IgemmP p) {
     ox = r & (p.Wo - 1);
     const int by = oy * s - pad, bx = ox * s - pad;
     const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
-    const float* xb = p.x + (((long long)b * p.H + by) * p.W + bx) * p.Cx + q * 4;
+    const long long xo = (((long long)b * p.H + by) * p.W + bx) * p.Cx + q * 4;
     for (int t = 0; t < p.T; ++t) {
       if (!((mask >> t) & 1u)) continue;
       int dy, dx;
       tap_delta(p.kind, kw, t, py, px, dy, dx);
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + ((long long)dy * p.W + dx) * p.Cx);
+      const long long xe = xo + ((long long)dy * p.W + dx) * p.Cx;
+      f32x4 xv;
+      if (p.x16) {
+        const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+        xv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+      } else {
+        xv = *reinterpret_cast<const f32x4*>(p.x + xe);
+      }
       const float* wp = wl + ((size_t)t * p.Ca + q * 4) * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc += xv[j] * *reinterpret_cast<const f32x4*>(wp + j * 4);
@@ -803,14 +823,15 @@ __global__ __launch_bounds__(256) void small_n_conv_kernel(IgemmP p) {
       if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
       else if (p.act == S2I_ACT_TANH) v = tanhf(v);
       else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
-      p.y[row * p.ldy + n] = v;
+      if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(v);
+      else p.y[row * p.ldy + n] = v;
     }
   }
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long long rows, int N,
                                      const float* __restrict__ bias, int act, float* __restrict__ y,
-                                     int ldy) {
+                                     int ldy, int y16) {
   const long long total = rows * N;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
@@ -822,7 +843,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long
     if (act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
     else if (act == S2I_ACT_TANH) v = tanhf(v);
     else if (act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
-    y[row * ldy + n] = v;
+    if (y16) reinterpret_cast<unsigned short*>(y)[row * ldy + n] = f2bf(v);
+    else y[row * ldy + n] = v;
   }
 }
 
@@ -831,7 +853,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ slab, int S, long long rows,
                                                                   int N, float* __restrict__ y, int ldy,
                                                                   float* __restrict__ part, int nparts, int cpb,
-                                                                  int ppg, long long Rg) {
+                                                                  int ppg, long long Rg, int y16) {
   __shared__ f32x4 sh[2][256];
   const int tid = threadIdx.x;
   const int rpb = 256 / cpb;
@@ -850,7 +872,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* _
       const float* sp = slab + row * N + quad * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(sp);
       for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(sp + s * sstride);
-      *reinterpret_cast<f32x4*>(y + row * ldy + quad * 4) = v;
+      if (y16) {
+        unsigned short* yp = reinterpret_cast<unsigned short*>(y) + row * ldy + quad * 4;
+        *reinterpret_cast<u32x2_t*>(yp) = u32x2_t{(unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16),
+                                                 (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16)};
+      } else {
+        *reinterpret_cast<f32x4*>(y + row * ldy + quad * 4) = v;
+      }
       s0 += v;
       s1 += v * v;
     }
@@ -879,6 +907,7 @@ struct WgradP {
   int Ho, Wo, lgWo, lgHoWo;
   int M, N, ldg, K, T, kind;
   int cps, nchunks;
+  int a16, g16;  // a / g hold bf16 instead of fp32
   unsigned a_bytes, c_bytes, g_bytes;
 };
 
@@ -934,13 +963,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
       const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
       const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       if (from_vec) ra[q] = bload4(rc_rs, ok ? b * p.Cc * 4 + ccolb : S2I_OOB);
-      else ra[q] = bload4(ra_rs, ok ? ((b * p.H + iy) * p.W + ix) * p.Ca * 4 + acolb : S2I_OOB);
+      else ra[q] = bload4_any(ra_rs, ok ? ((b * p.H + iy) * p.W + ix) * p.Ca * 4 + acolb : S2I_OOB, p.a16);
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int m = pc * 32 + brow + q * BROWS;
       if (BPRED && brow + q * BROWS >= 32) continue;
-      rb[q] = bload4(rg_rs, (m < p.M && nvalid) ? m * p.ldg * 4 + gcolb : S2I_OOB);
+      rb[q] = bload4_any(rg_rs, (m < p.M && nvalid) ? m * p.ldg * 4 + gcolb : S2I_OOB, p.g16);
     }
   };
 
@@ -1155,6 +1184,146 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
     }
 }
 
+// Weight gradient with BOTH operands stored as bf16 (bf16 activation mode): the structure of igemm_wgrad_split_kernel
+// with one plane, but the staged values are already bf16, so a 16-byte load (8 channels of one pixel) is copied to
+// LDS as it is, and a stage is 64 pixels deep (4 k-steps, 16 MFMAs per wave between two barriers instead of 8).
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 3) void igemm_wgrad_b16_kernel(WgradP p) {
+  constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int PC = 64;                               // pixels per stage
+  constexpr int AROWB = BM * 2, BROWB = BN * 2;
+  constexpr int AMASK = BM / 8 - 1, BMASK = BN / 8 - 1;
+  constexpr int ATPR = BM / 8, BTPR = BN / 8;          // threads per pixel row
+  constexpr int AROWS = 256 / ATPR, BROWS = 256 / BTPR;  // pixel rows per pass
+  constexpr int APASS = PC / AROWS, BPASS = (PC + BROWS - 1) / BROWS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PC * (AROWB + BROWB)];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + PC * AROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  int s, pad, kw;
+  geom(p.kind, s, pad, kw);
+  const int acol8 = tid % ATPR, arow = tid / ATPR;
+  const int bcol8 = tid % BTPR, brow = tid / BTPR;
+  const int kcol = k0 + acol8 * 8;
+  const bool kvalid = kcol < p.K;
+  int c = 0, dy = 0, dx = 0;
+  if (kvalid) {
+    const int t = kcol / p.Cin;
+    c = kcol - t * p.Cin;
+    dy = t / kw;
+    dx = t - dy * kw;
+  }
+  const int nb = n0 + bcol8 * 8;
+  const bool nvalid = nb < p.N;
+  const __amdgpu_buffer_rsrc_t ra_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, p.g_bytes, 0x00020000);
+  u32x4 ra[APASS], rb[BPASS];
+  auto fetch = [&](int pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      const int m = pc * PC + arow + q * AROWS;
+      const int b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+      const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
+      const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      ra[q] = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, ok ? (((b * p.H + iy) * p.W + ix) * p.Ca + c) * 2 : S2I_OOB, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int row = brow + q * BROWS;
+      const int m = pc * PC + row;
+      rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rg_rs, (row < PC && m < p.M && nvalid) ? (m * p.ldg + nb) * 2 : S2I_OOB, 0, 0);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int gi = lane & 15, gq = gi >> 2, gp = gi & 3;
+  const int gh = lane >> 5, gcb = (lane >> 4) & 1;
+  const int sw0 = (gq << 2) | (2 * gh);
+  int aad[TM][2], bad[TN][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int prow = 8 * gh + 4 * f + gq;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int ch = ((wm * TM + i) * 32 + 16 * gcb) / 8 + (gp >> 1);
+      aad[i][f] = prow * AROWB + 16 * ((ch ^ (sw0 | f)) & AMASK) + 8 * (gp & 1);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ch = ((wn * TN + j) * 32 + 16 * gcb) / 8 + (gp >> 1);
+      bad[j][f] = prow * BROWB + 16 * ((ch ^ (sw0 | f)) & BMASK) + 8 * (gp & 1);
+    }
+  }
+
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunks, c_begin + p.cps);
+  if (c_begin < c_end) fetch(c_begin);
+  for (int pc = c_begin; pc < c_end; ++pc) {
+#pragma unroll
+    for (int q = 0; q < APASS; ++q) {
+      const int row = arow + q * AROWS;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+      *reinterpret_cast<u32x4*>(As + row * AROWB + 16 * ((acol8 ^ sw) & AMASK)) = ra[q];
+    }
+#pragma unroll
+    for (int q = 0; q < BPASS; ++q) {
+      const int row = brow + q * BROWS;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+      if (row < PC) *reinterpret_cast<u32x4*>(Bs + row * BROWB + 16 * ((bcol8 ^ sw) & BMASK)) = rb[q];
+    }
+    __syncthreads();
+    if (pc + 1 < c_end) fetch(pc + 1);
+#pragma unroll
+    for (int ks = 0; ks < PC / 16; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const s16x4 lo = lds_tr_read(As + ks * 16 * AROWB + aad[i][0]);
+        const s16x4 hi = lds_tr_read(As + ks * 16 * AROWB + aad[i][1]);
+        a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const s16x4 lo = lds_tr_read(Bs + ks * 16 * BROWB + bad[j][0]);
+        const s16x4 hi = lds_tr_read(Bs + ks * 16 * BROWB + bad[j][1]);
+        b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* outp = p.slab + (size_t)split * p.K * p.N;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int krow = k0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (krow >= p.K) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * TN * 32 + j * 32 + l31;
+        if (n < p.N) outp[(size_t)krow * p.N + n] = acc[i][j][r];
+      }
+    }
+}
+
 // Weight gradient of a 3x3 stride-1 convolution over a wide map with few channels (the generator at 64x64 and
 // 128x128, Cin = 64 / 32).  The generic kernel above stages an im2col tile per chunk, i.e. it pulls every input pixel
 // through the vector-memory path once per tap; with K x N this small that path, not the matrix cores, is the limit
@@ -1313,7 +1482,14 @@ __global__ __launch_bounds__(256) void small_n_wgrad_kernel(WgradP p) {
     const int m = grp * PPW + pl;
     const int ix = m & wmask;
     const int iy = (m >> p.lgWo) & (p.H - 1);
-    const f32x4 av = *reinterpret_cast<const f32x4*>(p.a + (size_t)m * p.Ca + q * 4);
+    f32x4 av;
+    if (p.a16) {
+      const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.a) + (size_t)m * p.Ca + q * 4);
+      av = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                 __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+    } else {
+      av = *reinterpret_cast<const f32x4*>(p.a + (size_t)m * p.Ca + q * 4);
+    }
     const float* gp = p.g + (size_t)m * 4;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -1667,7 +1843,8 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
 
 static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                              const unsigned short* wsp, int planes, int np, int kp, const float* bias,
-                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream);
+                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream,
+                             int x16 = 0, int y16 = 0);
 
 extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                                     const float* bias, const float* cls_bias, float* y, float* part, void* ws,
@@ -1712,9 +1889,20 @@ static void launch_split(const IgemmP& p, dim3 grid, int planes, hipStream_t st)
   else hipLaunchKernelGGL((igemm_fwd_split_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), 0, st, p);
 }
 
+extern "C" int s2i_conv_forward_dt(const s2i_conv_desc* d, const void* x, int x_dtype, const float* cvec, const float* w,
+                                   const float* bias, const float* cls_bias, void* y, int y_dtype, float* part, void* ws,
+                                   size_t ws_bytes, void* stream) {
+  S2I_REQUIRE(w != nullptr, "conv: null weight");
+  S2I_REQUIRE((x_dtype == S2I_DT_F32 || x_dtype == S2I_DT_BF16) && (y_dtype == S2I_DT_F32 || y_dtype == S2I_DT_BF16),
+              "conv: unknown dtype");
+  return conv_forward_impl(d, (const float*)x, cvec, w, nullptr, 0, 0, 0, bias, cls_bias, (float*)y, part, ws, ws_bytes,
+                           stream, x_dtype == S2I_DT_BF16, y_dtype == S2I_DT_BF16);
+}
+
 static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                              const unsigned short* wsp, int planes, int np, int kp, const float* bias,
-                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream) {
+                             const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream,
+                             int x16, int y16) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 1;
   S2I_REQUIRE(!cls_bias || (d->kind == S2I_CONV_K3S1 && pl.splitk == 1), "conv: class bias needs an unsplit 3x3 conv");
@@ -1735,6 +1923,8 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   p.ldw = d->ldw; p.wR = d->wR; p.ldy = d->ldy; p.nparts = pl.gridM * pl.nphases;
   p.g_kw = d->kw; p.g_s = d->stride; p.g_pad = d->pad; p.wt = d->wmode != 0;
   p.Mrows = pl.Mrows;
+  p.x16 = x16; p.y16 = y16;
+  S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
   if (!wsp && d->N <= 4 && d->Cc == 0 && !d->stats && !cls_bias && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
       (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) && pl.M >= 4096) {
@@ -1752,7 +1942,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   const bool wt = d->wmode != 0;
   const int wtaps = d->kind == S2I_TCONV_K4S2 ? 16 : pl.T;
-  const unsigned long long xb = (unsigned long long)d->B * d->H * d->W * d->Cx * 4ull;
+  const unsigned long long xb = (unsigned long long)d->B * d->H * d->W * d->Cx * (x16 ? 2ull : 4ull);
   const unsigned long long wb = (unsigned long long)wtaps * d->wR * d->ldw * 4ull;
   S2I_REQUIRE(xb < 0x7ff00000ull && wb < 0x7ff00000ull, "conv: tensor exceeds the 2 GiB buffer-addressing window");
   p.x_bytes = (unsigned)xb;
@@ -1784,7 +1974,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
       const int nparts = stat_parts_for(pl, groups);
       hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(nparts, (Q + cpb - 1) / cpb), dim3(256), 0, st,
                          (const float*)ws, pl.splitk, pl.Mrows, d->N, y, d->ldy, part, nparts, cpb, nparts / groups,
-                         pl.Mrows / groups);
+                         pl.Mrows / groups, y16);
       S2I_LAUNCH_CHECK("splitk_reduce_stats");
       return 0;
     }
@@ -1792,8 +1982,9 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     int blocks = s2i_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, pl.splitk,
-                       pl.Mrows, d->N, bias, d->act, y, d->ldy);
+                       pl.Mrows, d->N, bias, d->act, y, d->ldy, y16);
     S2I_LAUNCH_CHECK("splitk_reduce");
+    S2I_REQUIRE(!(d->stats && y16), "conv: bf16 output with statistics needs N %% 4 == 0 on a split-K layer");
     if (d->stats) return s2i_colstats(y, pl.Mrows, d->N, d->ldy, part, stat_parts_for(pl, 1), stream);
   }
   return 0;
@@ -1806,7 +1997,21 @@ extern "C" size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d) {
 }
 
 static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
-                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16 = 0, int g16 = 0);
+
+extern "C" size_t s2i_wgrad_workspace_bytes_dt(const s2i_wgrad_desc* d, int a_dtype, int g_dtype) {
+  WgPlan pl;
+  if (plan_wgrad(d, &pl, (a_dtype || g_dtype) ? 1 : 0)) return 0;
+  return (size_t)pl.splitk * pl.K * d->N * sizeof(float);
+}
+
+extern "C" int s2i_conv_wgrad_dt(const s2i_wgrad_desc* d, const void* a, int a_dtype, const float* cvec, const void* g,
+                                 int g_dtype, float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  S2I_REQUIRE((a_dtype == S2I_DT_F32 || a_dtype == S2I_DT_BF16) && (g_dtype == S2I_DT_F32 || g_dtype == S2I_DT_BF16),
+              "wgrad: unknown dtype");
+  return conv_wgrad_impl(d, 0, (const float*)a, cvec, (const float*)g, grad_oihw, ws, ws_bytes, stream,
+                         a_dtype == S2I_DT_BF16, g_dtype == S2I_DT_BF16);
+}
 
 extern "C" int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
                               float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
@@ -1833,9 +2038,12 @@ static void launch_wgrad_split(const WgradP& p, dim3 grid, int planes, hipStream
 }
 
 static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
-                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16, int g16) {
   WgPlan pl;
-  if (plan_wgrad(d, &pl, planes)) return 1;
+  // bf16 operands: the plan of the split modes (no row-segment / 96-row tiles, which stage fp32 rows)
+  if (plan_wgrad(d, &pl, (planes || a16 || g16) ? 1 : 0)) return 1;
+  S2I_REQUIRE(!(planes && (a16 || g16)), "wgrad(split): bf16 tensors go through s2i_conv_wgrad_dt");
+  S2I_REQUIRE(!(pl.small_n && g16), "wgrad: the <= 4 channel gradient stream expects an fp32 output gradient");
   S2I_REQUIRE((a || d->Ca == 0) && g && grad_oihw, "wgrad: null operand");
   S2I_REQUIRE(d->Cc == 0 || cvec != nullptr, "wgrad: cvec is null but Cc > 0");
   const size_t need = (size_t)pl.splitk * pl.K * d->N * sizeof(float);
@@ -1847,15 +2055,29 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
   p.Ho = pl.Ho; p.Wo = pl.Wo; p.lgWo = s2i_ilog2(pl.Wo); p.lgHoWo = s2i_ilog2(pl.Ho * pl.Wo);
   p.M = pl.M; p.N = d->N; p.ldg = d->ldg; p.K = pl.K; p.T = pl.T; p.kind = d->kind;
   p.cps = pl.cps; p.nchunks = pl.nchunks;
+  p.a16 = a16; p.g16 = g16;
   {
-    const unsigned long long ab = (unsigned long long)d->B * d->H * d->W * d->Ca * 4ull;
-    const unsigned long long gb = (unsigned long long)pl.M * d->ldg * 4ull;
+    const unsigned long long ab = (unsigned long long)d->B * d->H * d->W * d->Ca * (a16 ? 2ull : 4ull);
+    const unsigned long long gb = (unsigned long long)pl.M * d->ldg * (g16 ? 2ull : 4ull);
     S2I_REQUIRE(ab < 0x7ff00000ull && gb < 0x7ff00000ull, "wgrad: tensor exceeds the 2 GiB buffer-addressing window");
     p.a_bytes = (unsigned)ab; p.g_bytes = (unsigned)gb;
     p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
-  if (pl.rows3) {
+  if (a16 && g16 && !pl.small_n && d->Cc == 0 && (pl.Cin % 8) == 0 && (d->N % 8) == 0 && (d->ldg % 8) == 0) {
+    // both operands bf16: 64-pixel stages on the bf16 matrix cores
+    WgradP q = p;
+    q.nchunks = s2i_cdiv(pl.M, 64);
+    q.cps = s2i_cdiv(q.nchunks, pl.splitk);
+    dim3 g16grid(pl.gridK, pl.gridN, s2i_cdiv(q.nchunks, q.cps));
+    S2I_REQUIRE((int)g16grid.z <= pl.splitk, "wgrad(bf16): split plan mismatch");
+    // slabs of splits that this plan does not launch must not be summed: shrink the slab count instead
+    pl.splitk = (int)g16grid.z;
+    if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 128, 2, 2>), g16grid, dim3(256), 0, st, q);
+    else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 64, 2, 2>), g16grid, dim3(256), 0, st, q);
+    else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 32, 4, 1>), g16grid, dim3(256), 0, st, q);
+    else hipLaunchKernelGGL((igemm_wgrad_b16_kernel<64, 64, 2, 2>), g16grid, dim3(256), 0, st, q);
+  } else if (pl.rows3) {
     dim3 g3(d->Ca == 32 ? 1 : 3, pl.gridN, pl.splitk);
     if (d->Ca == 32 && pl.bn3 == 64) hipLaunchKernelGGL((wgrad_k3_rows_kernel<32, 64, 3, 1, 3>), g3, dim3(192), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL((wgrad_k3_rows_kernel<32, 32, 3, 1, 3>), g3, dim3(192), 0, st, p);

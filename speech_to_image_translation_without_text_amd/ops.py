@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GLU, ACT_NONE, CONV_K1, CONV_K3S1, CONV_K4S2,
+from ._lib import (ACT_GLU, ACT_NONE, CONV_K1, CONV_K3S1, CONV_K4S2, DT_BF16, DT_F32,
                    PACK_PLAIN, PACK_UPFOLD, TCONV_K4S2, ConvDesc, WgradDesc, check, ptr, stream)
 
 BN_EPS = 1e-5
@@ -222,6 +222,134 @@ def split_weight(packed, planes, transpose):
     return cache[3] if transpose else cache[2]
 
 
+# ---- bf16 activation mode (BASELINE config 4) ------------------------------------------------------------------------
+# ACT_BF16 = True (S2I_ACT_BF16=1, bench.py --math bf16): activations between the fused blocks are stored as bf16 NHWC,
+# convolutions whose channel counts allow it run on the bf16 matrix cores from bf16 weights (s2i_conv_forward_bf16),
+# BatchNorm statistics come from the fp32 accumulators, master weights / gradients / Adam / EMA stay fp32.  fp32 islands:
+# CA_NET, INIT_STAGE_G's fc (+ BatchNorm1d), the NHWC4 image tensors, the logit heads and the losses.
+ACT_BF16 = os.environ.get("S2I_ACT_BF16", "0") == "1"
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return DT_BF16
+    if t.dtype != torch.float32:
+        raise _lib.S2IError("activation tensors are fp32 or bf16, got %s" % t.dtype)
+    return DT_F32
+
+
+def cast(t, dtype):
+    """Contiguous tensor in the other activation dtype (own kernel: torch is not on the product path for arithmetic)."""
+    if t.dtype == dtype:
+        return t
+    lib = _lib_ready()
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    n = t.numel()
+    if n % 4 != 0:
+        raise _lib.S2IError("cast: %d elements (not a multiple of 4)" % n)
+    check(lib.s2i_cast(ptr(t), _dt(t), ptr(out), _dt(out), n, stream()), "s2i_cast")
+    return out
+
+
+def bf16_weight(packed, d, w_offset):
+    """bf16 weights of one convolution descriptor in the stage order of s2i_conv_forward_bf16, cached on the packed fp32
+    tensor until it is re-packed (the fused Adam bumps `_s2i_gen`)."""
+    lib = _lib_ready()
+    cache = getattr(packed, '_s2i_b16', None)
+    gen = getattr(packed, '_s2i_gen', 0)
+    if cache is None or cache[0] != gen:
+        cache = (gen, {})
+        packed._s2i_b16 = cache
+    key = (d.kind, d.wmode, d.flip, d.Cx, d.N, int(w_offset))
+    ent = cache[1].get(key)
+    if ent is None:
+        old = getattr(packed, '_s2i_b16_bufs', None)
+        if old is None:
+            old = packed._s2i_b16_bufs = {}
+        ent = old.get(key)               # reuse the allocation across generations
+        n = lib.s2i_conv_bf16_weight_elems(ctypes.byref(d))
+        if n == 0:
+            check(1, "s2i_conv_bf16_weight_elems")
+        if ent is None or ent.numel() != n:
+            ent = torch.empty(n, dtype=torch.bfloat16, device=packed.device)
+            old[key] = ent
+        check(lib.s2i_pack_conv_weight_bf16(ctypes.byref(d), ptr(packed) + 4 * int(w_offset), packed.shape[1],
+                                            packed.shape[2], ptr(ent), stream()), "s2i_pack_conv_weight_bf16")
+        cache[1][key] = ent
+    return ent
+
+
+def conv_any(kind, x, packed, N, *, wmode=0, flip=0, bias=None, act=ACT_NONE, stats=False, groups=1, w_offset=0,
+             cls_bias=None, out_dtype=torch.float32):
+    """Convolution of an NHWC tensor of either activation dtype (no broadcast vector) -> (y, part, nparts).  bf16 in /
+    bf16 out goes to the patch-staged bf16 kernel when the layer is eligible, everything else to the fp32-MFMA kernel
+    reading / writing the given dtypes."""
+    lib = _lib_ready()
+    B, H, W, Cx = x.shape
+    Ho, Wo = _geom(kind, H, W)
+    wR, ldw = packed.shape[1], packed.shape[2]
+    d = ConvDesc(kind, B, H, W, Cx, 0, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
+                 1 if cls_bias is not None else 0, 0, 0, 0)
+    y = torch.empty((B, Ho, Wo, N), dtype=out_dtype, device=x.device)
+    fast = (x.dtype == torch.bfloat16 and out_dtype == torch.bfloat16 and bias is None and act == ACT_NONE
+            and N % 8 == 0 and lib.s2i_conv_bf16_eligible(ctypes.byref(d)))
+    if EXEC_LOG is not None:
+        T = _TAPS[kind]
+        _log_exec("conv%s k%d %s[%d,%d,%d,%d]->%d" % ("16" if fast else "", kind, "T" if wmode else "", B, H, W, Cx, N),
+                  B * Ho * Wo, N, T * Cx, x.numel(), T * Cx * N * (4 if kind == TCONV_K4S2 else 1), y.numel(),
+                  x.element_size(), y.element_size())
+    part, nparts = None, 0
+    if fast:
+        if stats:
+            nparts = lib.s2i_conv_bf16_stat_parts(ctypes.byref(d))
+            if nparts <= 0:
+                check(1, "s2i_conv_bf16_stat_parts")
+            part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
+        wb = bf16_weight(packed, d, w_offset)
+        ws = _ws.get(lib.s2i_conv_bf16_workspace_bytes(ctypes.byref(d)), x.device)
+        check(lib.s2i_conv_forward_bf16(ctypes.byref(d), ptr(x), ptr(wb), ptr(cls_bias), ptr(y), ptr(part), ptr(ws),
+                                        ws.numel() * 4, stream()), "s2i_conv_forward_bf16")
+        return y, part, nparts
+    if stats:
+        nparts = lib.s2i_conv_stat_parts(ctypes.byref(d))
+        if nparts <= 0:
+            check(1, "s2i_conv_stat_parts")
+        part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
+    ws = _ws.get(lib.s2i_conv_workspace_bytes(ctypes.byref(d)), x.device)
+    check(lib.s2i_conv_forward_dt(ctypes.byref(d), ptr(x), _dt(x), None, ptr(packed) + 4 * int(w_offset), ptr(bias),
+                                  ptr(cls_bias), ptr(y), _dt(y), ptr(part), ptr(ws), ws.numel() * 4, stream()),
+          "s2i_conv_forward_dt")
+    return y, part, nparts
+
+
+def wgrad_any(kind, a, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False, i_off=0, I_total=0):
+    """Weight gradient from operands of either activation dtype (no broadcast vector) into an fp32 OIHW tensor."""
+    lib = _lib_ready()
+    B, H, W, Ca = a.shape
+    N = g.shape[-1]
+    if len(grad_shape) == 2:
+        O, I, KH, KW = grad_shape[0], grad_shape[1], 1, 1
+    else:
+        O, I, KH, KW = grad_shape
+    d = WgradDesc(kind, B, H, W, Ca, 0, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0, i_off, I_total)
+    if EXEC_LOG is not None:
+        Ho, Wo = _geom(kind, H, W)
+        _log_exec("wgrad%s k%d a[%d,%d,%d,%d] g%d" % ("16" if a.dtype == g.dtype == torch.bfloat16 else "", kind, B, H, W,
+                                                      Ca, N), B * Ho * Wo, N, _TAPS[kind] * Ca, a.numel(), g.numel(),
+                  _TAPS[kind] * Ca * N, a.element_size(), 4)
+    if out is None:
+        full = grad_shape if not I_total else (O, I_total, KH, KW)
+        out = torch.empty(full, dtype=torch.float32, device=a.device)
+    wsb = lib.s2i_wgrad_workspace_bytes_dt(ctypes.byref(d), _dt(a), _dt(g))
+    if wsb == 0:
+        check(1, "s2i_wgrad_workspace_bytes_dt")
+    ws = _ws.get(wsb, a.device)
+    check(lib.s2i_conv_wgrad_dt(ctypes.byref(d), ptr(a), _dt(a), None, ptr(g), _dt(g), ptr(out), ptr(ws), ws.numel() * 4,
+                                stream()), "s2i_conv_wgrad_dt")
+    return out
+
+
 # ---- executed-work accounting ------------------------------------------------------------------------
 # bench.py / tools set EXEC_LOG to a list for the duration of ONE step: every matrix-product launch appends
 # (what, flops, bytes) with the multiply-add count the kernels really execute (2*M*N*K of the launched GEMM: up-blocks at
@@ -331,7 +459,7 @@ def _rows_view(t):
     if t.is_contiguous():
         return t, C
     st = t.stride()
-    if t.dim() >= 2 and st[-1] == 1 and st[-2] % 4 == 0 and t.data_ptr() % 16 == 0:
+    if t.dim() >= 2 and st[-1] == 1 and st[-2] % 4 == 0 and t.data_ptr() % (4 * t.element_size()) == 0:
         ld = st[-2]
         ok = True
         expect = ld
@@ -353,11 +481,17 @@ def _num_parts(M):
 _KIND = {"k1": CONV_K1, "k3s1": CONV_K3S1, "k4s2": CONV_K4S2, "up": TCONV_K4S2}
 
 
-def _dgrad(kind_name, dy, w, packed, n_in):
+_DGRAD = {"k3s1": (CONV_K3S1, 1), "k4s2": (TCONV_K4S2, 0), "up": (CONV_K4S2, 0), "k1": (CONV_K1, 0)}
+
+
+def _dgrad(kind_name, dy, w, packed, n_in, out_dtype=None):
     """Input gradient of the conv `kind_name` given dy (NHWC) -> [B,H,W,n_in]."""
     Op = packed.shape[2]
     if dy.shape[-1] != Op:
         raise _lib.S2IError("dgrad: dy has %d channels, packed weight %d" % (dy.shape[-1], Op))
+    if out_dtype is not None:     # bf16 activation mode: either dtype on either side
+        kind, flip = _DGRAD[kind_name]
+        return conv_any(kind, dy, packed, n_in, wmode=1, flip=flip, out_dtype=out_dtype)[0]
     if kind_name == "k3s1":
         y, _, _ = conv_raw(CONV_K3S1, dy, None, packed, n_in, wmode=1, flip=1, wR=packed.shape[1], ldw=Op)
     elif kind_name == "k4s2":
@@ -374,6 +508,12 @@ def _wgrad(kind_name, x, cvec, dy, weight):
     out, acc = (weight.grad, True) if _direct(weight) else (None, False)
 
     def run():
+        if x.dtype == torch.bfloat16 or dy.dtype == torch.bfloat16:
+            if cvec is not None:
+                raise _lib.S2IError("wgrad: bf16 operands carry their broadcast vector materialised")
+            if kind_name == "up":
+                return wgrad_any(CONV_K4S2, dy, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
+            return wgrad_any(_KIND[kind_name], x, dy, tuple(weight.shape), out=out, accumulate=acc)
         if kind_name == "up":
             return wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
         return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
@@ -398,13 +538,13 @@ def _split_input_grad(dx_full, Cc):
     lib = _lib_ready()
     B, H, W, Ca = dx_full.shape
     if H * W == 1:
-        dc = dx_full.reshape(B, Ca)[:, :Cc]
+        dc = dx_full.reshape(B, Ca)[:, :Cc].float()
     else:
         dc = torch.empty((B, Cc), dtype=torch.float32, device=dx_full.device)
         wsb = lib.s2i_spatial_sum_workspace_bytes(B, H * W, Cc)
         ws = _ws.get(wsb, dx_full.device)
-        check(lib.s2i_spatial_sum(ptr(dx_full), Ca, B, H * W, Cc, ptr(dc), ptr(ws), ws.numel() * 4, stream()),
-              "s2i_spatial_sum")
+        check(lib.s2i_spatial_sum_dt(_dt(dx_full), ptr(dx_full), Ca, B, H * W, Cc, ptr(dc), ptr(ws), ws.numel() * 4,
+                                     stream()), "s2i_spatial_sum")
     return dx_full[..., Cc:], dc
 
 
@@ -421,7 +561,7 @@ def _tap_sums(dy):
     out = torch.empty((B, 9, C), dtype=torch.float32, device=dy.device)
     wsb = lib.s2i_border_sums_workspace_bytes(B, H, W, C)
     ws = _ws.get(wsb, dy.device)
-    check(lib.s2i_tap_sums(ptr(dy), B, H, W, C, ptr(out), ptr(ws), ws.numel() * 4, stream()), "s2i_tap_sums")
+    check(lib.s2i_tap_sums_dt(_dt(dy), ptr(dy), B, H, W, C, ptr(out), ptr(ws), ws.numel() * 4, stream()), "s2i_tap_sums")
     return out
 
 
@@ -436,6 +576,19 @@ class ConvBnAct(torch.autograd.Function):
         packed = packed_weight(weight, PACK_UPFOLD if kind_name == "up" else PACK_PLAIN)
         Cout = weight.shape[0]
         factored = _factor_cvec(kind_name, cvec, x)
+        # bf16 activation mode: every spatial block stores its raw conv output and its result as bf16 (the fc of
+        # INIT_STAGE_G, kind k1, stays an fp32 island)
+        bf = (ACT_BF16 and kind_name != "k1") or x.dtype == torch.bfloat16
+        adt = torch.bfloat16 if bf else torch.float32
+        cat_cc = 0
+        if bf and cvec is not None and not factored:
+            # D's jointConv on 4x4 maps: the (c_code, h) concat of model.py:434 is materialised (a few MB) in bf16
+            B_, H_, W_, _ = x.shape
+            cat_cc = cvec.shape[1]
+            x = torch.cat((cast(cvec, adt).view(B_, 1, 1, cat_cc).expand(B_, H_, W_, cat_cc), cast(x, adt)), 3).contiguous()
+            cvec_used = None
+        else:
+            cvec_used = cvec
         if factored:
             B, Cc = cvec.shape
             Ip, Op = packed.shape[1], packed.shape[2]
@@ -443,8 +596,14 @@ class ConvBnAct(torch.autograd.Function):
             ws = _ws.get(B * 9 * Cout * 4, x.device)
             check(lib.s2i_cvec_bias_table(ptr(cvec), ptr(packed), B, Cc, Ip, Op, Cout, ptr(table), ptr(ws),
                                           ws.numel() * 4, stream()), "s2i_cvec_bias_table")
-            y, part, nparts = conv_raw(kind, x, None, packed, Cout, wR=Ip, ldw=Op, stats=training, groups=groups,
-                                       w_offset=Cc * Op, cls_bias=table)
+            if bf:
+                y, part, nparts = conv_any(kind, x, packed, Cout, stats=training, groups=groups, w_offset=Cc * Op,
+                                           cls_bias=table, out_dtype=adt)
+            else:
+                y, part, nparts = conv_raw(kind, x, None, packed, Cout, wR=Ip, ldw=Op, stats=training, groups=groups,
+                                           w_offset=Cc * Op, cls_bias=table)
+        elif bf:
+            y, part, nparts = conv_any(kind, x, packed, Cout, stats=training, groups=groups, out_dtype=adt)
         else:
             y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2],
                                        stats=training, groups=groups)
@@ -460,16 +619,17 @@ class ConvBnAct(torch.autograd.Function):
             check(lib.s2i_bn_eval_coeffs(Cout, ptr(gamma), ptr(beta), ptr(rm), ptr(rv), BN_EPS, ptr(coef), stream()),
                   "s2i_bn_eval_coeffs")
         Cact = Cout // 2 if act == ACT_GLU else Cout
-        out = torch.empty(y.shape[:-1] + (Cact,), dtype=torch.float32, device=x.device)
+        out = torch.empty(y.shape[:-1] + (Cact,), dtype=adt, device=x.device)
         if residual is not None:
-            residual = residual.contiguous()
-        check(lib.s2i_bn_act_forward(ptr(y), M, groups, Cout, ptr(coef), act, ptr(residual), ptr(out), stream()),
-              "s2i_bn_act_forward")
-        ctx.save_for_backward(x, cvec, weight, gamma, y, coef)
+            residual = cast(residual, adt).contiguous()
+        check(lib.s2i_bn_act_forward_dt(_dt(y), ptr(y), M, groups, Cout, ptr(coef), act, ptr(residual), ptr(out),
+                                        stream()), "s2i_bn_act_forward")
+        ctx.save_for_backward(x, cvec_used, weight, gamma, y, coef)
         ctx.beta_ref = beta
         ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
         ctx.groups = groups
         ctx.factored = factored
+        ctx.bf, ctx.cat_cc = bf, cat_cc
         return out
 
     @staticmethod
@@ -480,12 +640,14 @@ class ConvBnAct(torch.autograd.Function):
             raise _lib.S2IError("ConvBnAct.backward: eval-mode BatchNorm has no backward on this path")
         Cout = weight.shape[0]
         M = y.numel() // Cout
+        if dout.dtype != y.dtype:
+            dout = cast(dout, y.dtype)
         dout_k, ldd = _rows_view(dout)
         G = ctx.groups
         nparts = _num_parts(M // G) * G
         part = torch.empty((2, nparts, Cout), dtype=torch.float32, device=y.device)
-        check(lib.s2i_bn_act_bwd_reduce(ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ctx.act, ptr(part), nparts,
-                                        stream()), "s2i_bn_act_bwd_reduce")
+        check(lib.s2i_bn_act_bwd_reduce_dt(_dt(y), ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ctx.act, ptr(part),
+                                           nparts, stream()), "s2i_bn_act_bwd_reduce")
         beta = ctx.beta_ref
         need_gb = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         direct_bn = need_gb and _direct(gamma) and _direct(beta)
@@ -500,24 +662,46 @@ class ConvBnAct(torch.autograd.Function):
         if direct_bn:
             dgamma = dbeta = None
         dy = torch.empty_like(y)
-        check(lib.s2i_bn_act_bwd_apply(ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ptr(red2), ctx.act, ptr(dy),
-                                       stream()), "s2i_bn_act_bwd_apply")
+        check(lib.s2i_bn_act_bwd_apply_dt(_dt(y), ptr(y), ptr(dout_k), ldd, M, G, Cout, ptr(coef), ptr(red2), ctx.act,
+                                          ptr(dy), stream()), "s2i_bn_act_bwd_apply")
         need_x, need_c, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dc = dw = None
         Cc = 0 if cvec is None else cvec.shape[1]
+        bf = ctx.bf
+        if bf and not ctx.factored:
+            # bf16 activation mode; a broadcast vector (ctx.cat_cc channels) was concatenated in front of x in the forward
+            cc = ctx.cat_cc
+            if need_x or (need_c and cc):
+                packed = packed_weight(weight, PACK_UPFOLD if ctx.kind_name == "up" else PACK_PLAIN)
+                dx_full = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1], out_dtype=x.dtype)
+                dx, dc = _split_input_grad(dx_full, cc)
+                if not need_x:
+                    dx = None
+                if not need_c:
+                    dc = None
+            if need_w:
+                dw = _wgrad(ctx.kind_name, x, None, dy, weight)
+            dres = dout if ctx.has_res else None
+            return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None
         if ctx.factored:
             packed = packed_weight(weight, PACK_PLAIN)
             Ip, Op = packed.shape[1], packed.shape[2]
             B, Cx = x.shape[0], x.shape[-1]
             if need_x:
-                dx, _, _ = conv_raw(CONV_K3S1, dy, None, packed, Cx, wmode=1, flip=1, wR=Ip, ldw=Op, w_offset=Cc * Op)
+                if bf:
+                    dx = conv_any(CONV_K3S1, dy, packed, Cx, wmode=1, flip=1, w_offset=Cc * Op, out_dtype=x.dtype)[0]
+                else:
+                    dx, _, _ = conv_raw(CONV_K3S1, dy, None, packed, Cx, wmode=1, flip=1, wR=Ip, ldw=Op, w_offset=Cc * Op)
             if need_c or need_w:
                 tapsum = _tap_sums(dy)
                 direct = need_w and _direct(weight)
                 if need_w:
                     dw = weight.grad if direct else torch.empty(tuple(weight.shape), dtype=torch.float32, device=x.device)
-                    wgrad_raw(CONV_K3S1, x, None, dy, (Cout, Cx, 3, 3), out=dw, accumulate=direct, i_off=Cc,
-                              I_total=Cc + Cx)
+                    if bf:
+                        wgrad_any(CONV_K3S1, x, dy, (Cout, Cx, 3, 3), out=dw, accumulate=direct, i_off=Cc, I_total=Cc + Cx)
+                    else:
+                        wgrad_raw(CONV_K3S1, x, None, dy, (Cout, Cx, 3, 3), out=dw, accumulate=direct, i_off=Cc,
+                                  I_total=Cc + Cx)
                 if need_c:
                     dc = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
                 check(lib.s2i_cvec_grads(ptr(cvec), ptr(packed), ptr(tapsum), B, Cc, Ip, Op, Cout, Cout, Cc + Cx, ptr(dc),
@@ -544,7 +728,12 @@ class ConvAct(torch.autograd.Function):
         x = x.contiguous()
         kind = _KIND[kind_name]
         packed = packed_weight(weight, PACK_PLAIN)
-        out, _, _ = conv_raw(kind, x, None, packed, n_out, wR=packed.shape[1], ldw=packed.shape[2], bias=bias, act=act)
+        if (ACT_BF16 and kind_name != "k1") or x.dtype == torch.bfloat16:
+            # bf16 activation mode: feature maps (>= 8 channels) are bf16, NHWC4 images stay fp32
+            odt = torch.bfloat16 if n_out >= 8 else torch.float32
+            out = conv_any(kind, x, packed, n_out, bias=bias, act=act, out_dtype=odt)[0]
+        else:
+            out, _, _ = conv_raw(kind, x, None, packed, n_out, wR=packed.shape[1], ldw=packed.shape[2], bias=bias, act=act)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         ctx.kind_name, ctx.act, ctx.has_bias, ctx.n_out = kind_name, act, bias is not None, n_out
         return out
@@ -555,22 +744,25 @@ class ConvAct(torch.autograd.Function):
         x, weight, out = ctx.saved_tensors
         N = ctx.n_out
         M = dout.numel() // N
+        if out is not None and dout.dtype != out.dtype:
+            dout = cast(dout, out.dtype)
         dout_k, ldd = _rows_view(dout)
         if ctx.act != ACT_NONE:
-            dy = torch.empty(dout.shape, dtype=torch.float32, device=dout.device)
-            check(lib.s2i_act_backward(ptr(out), ptr(dout_k), ldd, M, N, ctx.act, ptr(dy), stream()),
+            dy = torch.empty(dout.shape, dtype=dout.dtype, device=dout.device)
+            check(lib.s2i_act_backward_dt(_dt(out), ptr(out), ptr(dout_k), ldd, M, N, ctx.act, ptr(dy), stream()),
                   "s2i_act_backward")
         else:
             dy = dout_k if ldd == N else dout_k.contiguous()
         dx = dw = db = None
+        mixed = x.dtype == torch.bfloat16 or dy.dtype == torch.bfloat16
         if ctx.needs_input_grad[0]:
             packed = packed_weight(weight, PACK_PLAIN)
-            dx = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1])
+            dx = _dgrad(ctx.kind_name, dy, weight, packed, x.shape[-1], out_dtype=x.dtype if mixed else None)
         if ctx.needs_input_grad[1]:
             dw = _wgrad(ctx.kind_name, x, None, dy, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             part = torch.empty((2, 1, N), dtype=torch.float32, device=dy.device)
-            check(lib.s2i_colstats(ptr(dy), M, N, N, ptr(part), 1, stream()), "s2i_colstats")
+            check(lib.s2i_colstats(ptr(cast(dy, torch.float32)), M, N, N, ptr(part), 1, stream()), "s2i_colstats")
             db = part[0, 0, :weight.shape[0]].clone()
         return dx, dw, db, None, None, None
 
@@ -658,7 +850,8 @@ class LogitHead(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         lib = _lib_ready()
-        x = x.contiguous()
+        ctx.x_dtype = x.dtype
+        x = cast(x.contiguous(), torch.float32)   # a (B,4,4,C) map: the heads and the losses are an fp32 island
         B, H, W, C = x.shape
         if H != 4 or W != 4 or tuple(weight.shape) != (1, C, 4, 4):
             raise _lib.S2IError("LogitHead: expects a 4x4 map and a (1,C,4,4) weight")
@@ -689,6 +882,8 @@ class LogitHead(torch.autograd.Function):
                                      ptr(dx), 0, ptr(dw), ptr(db), 1 if direct else 0, stream()), "s2i_logit_backward")
         if direct:
             dw = db = None
+        if dx is not None:
+            dx = cast(dx, ctx.x_dtype)
         return dx, dw, db
 
 
@@ -798,8 +993,10 @@ class ToNHWC(torch.autograd.Function):
         lib = _lib_ready()
         x = x.contiguous()
         B, C, H, W = x.shape
-        out = torch.empty((B, H, W, Cp), dtype=torch.float32, device=x.device)
-        check(lib.s2i_nchw_to_nhwc(ptr(x), ptr(out), B, C, H, W, Cp, stream()), "s2i_nchw_to_nhwc")
+        # bf16 activation mode: feature maps become bf16 here; NHWC4 images stay fp32
+        odt = torch.bfloat16 if (ACT_BF16 and Cp >= 8) else torch.float32
+        out = torch.empty((B, H, W, Cp), dtype=odt, device=x.device)
+        check(lib.s2i_nchw_to_nhwc_dt(_dt(out), ptr(x), ptr(out), B, C, H, W, Cp, stream()), "s2i_nchw_to_nhwc")
         ctx.C = C
         return out
 
@@ -809,7 +1006,7 @@ class ToNHWC(torch.autograd.Function):
         dk, ld = _rows_view(dout)
         B, H, W, _ = dout.shape
         dx = torch.empty((B, ctx.C, H, W), dtype=torch.float32, device=dout.device)
-        check(lib.s2i_nhwc_to_nchw(ptr(dk), ld, ptr(dx), B, ctx.C, H, W, stream()), "s2i_nhwc_to_nchw")
+        check(lib.s2i_nhwc_to_nchw_dt(_dt(dk), ptr(dk), ld, ptr(dx), B, ctx.C, H, W, stream()), "s2i_nhwc_to_nchw")
         return dx, None
 
 
@@ -822,8 +1019,8 @@ class ToNCHW(torch.autograd.Function):
         xk, ld = _rows_view(x)
         B, H, W, Cp = x.shape
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
-        check(lib.s2i_nhwc_to_nchw(ptr(xk), ld, ptr(out), B, C, H, W, stream()), "s2i_nhwc_to_nchw")
-        ctx.Cp = Cp
+        check(lib.s2i_nhwc_to_nchw_dt(_dt(xk), ptr(xk), ld, ptr(out), B, C, H, W, stream()), "s2i_nhwc_to_nchw")
+        ctx.Cp, ctx.x_dtype = Cp, x.dtype
         return out
 
     @staticmethod
@@ -831,8 +1028,8 @@ class ToNCHW(torch.autograd.Function):
         lib = _lib_ready()
         dout = dout.contiguous()
         B, C, H, W = dout.shape
-        dx = torch.empty((B, H, W, ctx.Cp), dtype=torch.float32, device=dout.device)
-        check(lib.s2i_nchw_to_nhwc(ptr(dout), ptr(dx), B, C, H, W, ctx.Cp, stream()), "s2i_nchw_to_nhwc")
+        dx = torch.empty((B, H, W, ctx.Cp), dtype=ctx.x_dtype, device=dout.device)
+        check(lib.s2i_nchw_to_nhwc_dt(_dt(dx), ptr(dout), ptr(dx), B, C, H, W, ctx.Cp, stream()), "s2i_nchw_to_nhwc")
         return dx, None
 
 

@@ -166,8 +166,9 @@ def test_generator_gradients_against_oracle(gpu):
     for k, g in oout['grad_g'].items():
         worst = max(worst, float((named[k].grad.cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30)))
     print("G gradients through identical discriminators: worst relative L2 deviation %.2e" % worst)
+    # same discriminators on both sides: 2e-3 (measured 1.7e-4); element-wise bounds: tests/test_parity_gpu.py
     for k, g in oout['grad_g'].items():
-        assert_close_l2(named[k].grad.cpu(), g, 1e-2, what="dG/" + k)
+        assert_close_l2(named[k].grad.cpu(), g, 2e-3, what="dG/" + k)
     for key in gold.files:
         if key.startswith('g_grad/'):
             k = key[len('g_grad/'):]

@@ -448,9 +448,10 @@ def test_reference_style_trainer_without_flat_buffers(gpu):
 def test_ragged_batch_full_train_step(gpu, B):
     """Last batch of an epoch (8855 % 24 = 23 on CUB, trainer.py:543-545; odd DistributedSampler shards): a full
     iteration with CAL_LOSS > 0 at a batch that is not a multiple of 4 (un-stacked D passes, padded class-aware
-    backward) against the oracle."""
+    backward) against the oracle.  The G update runs through the ORACLE's updated discriminators on both sides (the
+    first Adam step moves weights by lr * sign(g), test_model_gpu.py), so its gradients compare tightly."""
     from oracle import stackgan_oracle as orc
-    from speech_to_image_translation_without_text_amd import trainer as T
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
     case = dict(CASES['small3'], B=B)
     netG, netsD = build_nets(case)
     batch = make_batch(case)
@@ -465,18 +466,24 @@ def test_ragged_batch_full_train_step(gpu, B):
     tr.flatG.lr = 0.0
     b = to_dev(batch, gpu)
     emb = b['emb'].clone().requires_grad_(True)
-    errD, errG, kl = tr.train_step(b['real'], b['wrong'], emb, batch['labels'], b['noise'], b['eps'])
+    with ops.param_grad_mode(True):
+        tr.real_imgs, tr.wrong_imgs, tr.class_labels = b['real'], b['wrong'], batch['labels']
+        tr.fake_imgs, tr.mu, tr.logvar = netG(b['noise'], emb, b['eps'])
+        errD = sum(tr.train_Dnet(i, 0) for i in range(3))
+        for i, flat in enumerate(tr.flatsD):
+            for k, p_ in netsD[i].named_parameters():
+                p_.data.copy_(ostate.ds[i][k].to(gpu))
+            ops.refresh_packed(flat.params)
+        kl, errG = tr.train_Gnet(0)
     torch.cuda.synchronize()
     for i in range(3):
         assert_close(tr.fake_imgs[i], oout['fake'][i], rtol=1e-3, atol=1e-4, what="img%d B=%d" % (i, B))
     assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total B=%d" % B)
     assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total B=%d" % B)
-    assert_close_l2(emb.grad, oout['grad_emb'], 6e-2, what="grad_emb B=%d" % B)
-    # end to end (through discriminators that each side updated itself: first-step Adam moves weights by lr * sign(g),
-    # test_model_gpu.py): norm-wise, as for grad_emb; the element-wise bound is held by the segmented tests above
+    assert_close_l2(emb.grad, oout['grad_emb'], 2e-3, what="grad_emb B=%d" % B)
     named = dict(netG.named_parameters())
     for k, g in oout['grad_g'].items():
-        assert_close_l2(named[k].grad.cpu(), g, 6e-2, what="dG/%s B=%d" % (k, B))
+        assert_close_l2(named[k].grad.cpu(), g, 2e-3, what="dG/%s B=%d" % (k, B))
 
 
 def test_step_scopes_the_direct_gradient_switches(gpu):
