@@ -73,11 +73,57 @@ def profiled_numbers(key):
         return None
 
 
+def _time_launch(fn, reps=20):
+    for _ in range(3):
+        fn()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def bf16_kernel_roofline(dev, B):
+    """bf16 mode (BASELINE config 4): live HIP-event timing of the dominant kernel, conv_bf16_kernel, on its heaviest
+    launch of the step: D_NET256's Conv2d(64,128,k4,s2,p1) on the stacked (real | wrong | fake) batch, (3B,128,128,64)
+    bf16 NHWC.  Algorithmic bytes per launch (SURVEY.md section 8d rule at 2 B / element): the input read once, the raw
+    output written once, the bf16 weights read once."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K4S2, PACK_PLAIN
+    n = 3 * B
+    x = torch.randn(n, 128, 128, 64, device=dev).to(torch.bfloat16)
+    w = torch.randn(128, 64, 4, 4, device=dev) * 0.03
+    packed = ops.pack_weight(w, PACK_PLAIN)
+    fn = lambda: ops.conv_any(CONV_K4S2, x, packed, 128, stats=True, groups=3, out_dtype=torch.bfloat16)
+    ms = _time_launch(fn)
+    flops = 2.0 * (n * 64 * 64) * 128 * (16 * 64)
+    abytes = x.numel() * 2 + n * 64 * 64 * 128 * 2 + 16 * 64 * 128 * 2
+    gbs = abytes / (ms * 1e-3) / 1e9
+    prof = profiled_numbers("bf16_b%d" % B) or {}
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
+            "frac_profiled": round(abytes / (prof["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4) if prof.get("avg_ns") else None,
+            "profiled_source": prof.get("avg_source"),
+            "kernel": "conv_bf16_kernel<K4S2,128,16> (v_mfma_f32_32x32x16_bf16, LDS-staged 10x66-pixel input patch)",
+            "algorithmic_bytes": abytes,
+            "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (ms * 1e-3) / 2.5e15, 4),
+            "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) bf16 NHWC, %.1f MB algorithmic, %.2f GFLOP, %.3f ms"
+                      % (n, abytes / 1e6, flops / 1e9, ms),
+            "note": "this layer sits at the bf16 ridge (341 FLOP/B against 312): both fractions are reported"}
+
+
 def dominant_kernel_roofline(dev, B, math="f32"):
     """Live HIP-event timing of the dominant kernel: the fp32-MFMA implicit-GEMM convolution, on the
     heaviest single layer of the step (D_NET256 img_code_s16[2]: Conv2d(64,128,k4,s2,p1) on 128x128)."""
     from speech_to_image_translation_without_text_amd import ops
     from speech_to_image_translation_without_text_amd._lib import CONV_K4S2, PACK_PLAIN
+    if math == "bf16":
+        return bf16_kernel_roofline(dev, B)
+    if math == "bf16p":
+        math = "bf16"
     x = torch.randn(B, 128, 128, 64, device=dev)
     w = torch.randn(128, 64, 4, 4, device=dev) * 0.03
     packed = ops.pack_weight(w, PACK_PLAIN)
@@ -120,9 +166,13 @@ MATH_NOTE = {
     "f32": "v_mfma_f32_32x32x2_f32 (fp32 operands, fp32 accumulate)",
     "bf16x3": "each fp32 operand split into 3 bf16 planes, 6 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; "
               "error against fp64 <= that of the native fp32 MFMA path (tools/split_bench.py); opt-in (S2I_MATH_PLANES=3)",
-    "bf16": "operands of the conv GEMMs rounded to bf16 (one plane) on v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations, "
-            "BatchNorm statistics, master weights and Adam stay fp32 (the matrix-product half of BASELINE config 4; "
-            "activations are NOT stored in bf16); opt-in (S2I_MATH_PLANES=1)",
+    "bf16": "BASELINE config 4: activations and conv weights stored as bf16 in HBM, v_mfma_f32_32x32x16_bf16 with fp32 "
+            "accumulate (patch-staged conv_bf16_kernel / igemm_wgrad_b16_kernel), BatchNorm statistics from the fp32 "
+            "accumulators, fp32 master weights / gradients / Adam / EMA; fp32 islands: CA_NET, INIT_STAGE_G.fc, NHWC4 images, "
+            "logit heads and losses (S2I_ACT_BF16=1)",
+    "bf16p": "operands of the conv GEMMs rounded to bf16 (one plane) on v_mfma_f32_32x32x16_bf16, fp32 accumulate; activations, "
+             "BatchNorm statistics, master weights and Adam stay fp32 in HBM (round 1's matrix-product half of config 4; "
+             "S2I_MATH_PLANES=1)",
     "bf16x2": "each fp32 operand split into 2 bf16 planes, 3 cross products, fp32 accumulate; ~2^-16 relative per product "
               "(TF32-class, does not hold the 1e-3 parity tolerance end to end); opt-in (S2I_MATH_PLANES=2)",
 }
@@ -262,15 +312,22 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         step_flops = FLOP_PER_IMAGE * B
+        # SURVEY.md section 8d byte rule: activations 836.6 MB / image / step at 4 B per element (2 B in bf16 mode), weights
+        # 4852.7 MB per step (bf16 copies: half), Adam 3277.9 MB and EMA 254.9 MB (fp32 in both modes)
+        esz = 0.5 if args.math == "bf16" else 1.0
+        step_bytes = (836.6e6 * B + 4852.7e6) * esz + 3277.9e6 + 254.9e6
         line = {
             "metric": "StackGAN-v2 3-stage G+D train-step images/sec at 256px",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16 products / f32"}.get(args.math, "f32 as " + args.math), "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16": "bf16", "bf16p": "bf16 products / f32 storage"}.get(
+                args.math, "f32 as " + args.math), "data": "synthetic",
             "config": {"workload": "cfg/birds_3stages.yml: branch_num=3 (64/128/256 px), batch %d per GPU, %s, "
                                    "random-init weights (seed 0, weights_init), synthetic 1024-d embeddings + noise"
-                                   % (B, "fp32" if args.math != "bf16" else "bf16 matrix products with fp32 accumulate, "
-                                                                            "fp32 activations / master weights / Adam"),
+                                   % (B, {"bf16": "bf16 activations / weights in HBM, bf16 MFMA with fp32 accumulate, fp32 "
+                                                  "BatchNorm statistics / master weights / Adam (BASELINE config 4)",
+                                          "bf16p": "bf16 matrix products with fp32 accumulate, fp32 activations / master "
+                                                   "weights / Adam"}.get(args.math, "fp32")),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math]},
             "step_roofline": {
@@ -283,7 +340,8 @@ def main():
                 # the reference's own FLOP count for the same step: what a literal execution would need
                 "algorithmic_equiv_tflops": round(step_flops / (ms * 1e-3) / 1e12, 2),
                 "algorithmic_equiv_frac": round(step_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
-                "hbm_frac_of_8TBs": round(BYTES_PER_STEP_B24 * (B / 24.0) / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                "hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                "algorithmic_gbytes_per_step": round(step_bytes / 1e9, 2),
                 "note": "executed_* = 2*M*N*K over the launched GEMM descriptors of one step; algorithmic_equiv_* credits "
                         "the reference's 1.4264e11 FLOP/img/step (SURVEY.md §8d) and is NOT matrix-core utilisation; "
                         "bytes 28.46 GB per B=24 step (fp32 rule of §8d)"},
