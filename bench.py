@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): capture the single-GPU step in a hipGraph after the first warm-up steps and replay it; "
+                         "0: enqueue every launch from Python")
     ap.add_argument("--no-side-leg", action="store_true", help="skip the extra bf16x3 measurement of f32 runs (profiling)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16", "bf16p"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
@@ -246,6 +249,8 @@ def main():
         d.to(dev)
     tr = T.condGANTrainer(None, None, 256, False, local_rank=local_rank, distributed=distributed)
     tr.build(netG, netsD)
+    if args.graph and not distributed:
+        tr.enable_graph(warmup=2)
 
     t_start = time.perf_counter()
     batch, gen = synthetic_batch(B, dev, 1 + rank)
@@ -301,10 +306,12 @@ def main():
         raise RuntimeError("non-finite losses after the timed region: %s" % losses)
 
     # executed work of ONE step, from the descriptors of the launches themselves (outside the timed region)
+    graph_state, tr._graph = tr._graph, None   # the logged step is enqueued from Python (a graph replay runs no host code)
     ops.EXEC_LOG = []
     one_step()
     torch.cuda.synchronize()
     exec_log, ops.EXEC_LOG = ops.EXEC_LOG, None
+    tr._graph = graph_state
     exec_flops = sum(r[1] for r in exec_log)
 
     if rank == 0:
@@ -329,7 +336,8 @@ def main():
                                           "bf16p": "bf16 matrix products with fp32 accumulate, fp32 activations / master "
                                                    "weights / Adam"}.get(args.math, "fp32")),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
-                       "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math]},
+                       "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math],
+                       "hip_graph": bool(tr._graph is not None and tr._graph.get("graph") is not None)},
             "step_roofline": {
                 # what the matrix cores really deliver: multiply-adds of the launched GEMMs (up-blocks at 4 taps per
                 # output parity, c_code folded into a class bias, no D weight gradients in the G update)
@@ -360,7 +368,9 @@ def main():
                 # reported beside the value, never as the value: the same step with the split-bf16 matrix products
                 try:
                     ops.MATH_PLANES = 3
-                    el3, out3 = timed(3, args.steps)
+                    if tr._graph is not None:
+                        tr.enable_graph(warmup=2)   # a graph of its own for this mode
+                    el3, out3 = timed(4, args.steps)
                     line["bf16x3_split"] = {"value": round(B * args.steps / el3, 2), "unit": "images/sec",
                                             "ms_per_step": round(el3 / args.steps * 1e3, 3), "note": MATH_NOTE["bf16x3"]}
                 except Exception as e:  # noqa: BLE001 - the headline number must not depend on this extra leg

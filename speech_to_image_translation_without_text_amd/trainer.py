@@ -245,6 +245,11 @@ class condGANTrainer(object):
         # independent discriminator passes on separate HIP streams (S2I_D_STREAMS=0 turns it off)
         self.d_streams = os.environ.get("S2I_D_STREAMS", "1") == "1" and torch.cuda.is_available()
         self._side_streams = None
+        # hipGraph replay of the single-GPU step (S2I_GRAPH=1 or enable_graph()): the step has no host synchronisation and
+        # a device-side Adam counter, so after a few eager warm-up steps it is captured once and replayed
+        self._graph = None
+        if os.environ.get("S2I_GRAPH", "0") == "1":
+            self.enable_graph()
 
     def _make_d_streams(self):
         """One stream per discriminator; the largest one is the critical path of the step and gets the high priority,
@@ -452,7 +457,70 @@ class condGANTrainer(object):
         return kl_loss, errG_total
 
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
+    def enable_graph(self, warmup=3):
+        """Capture the train step in a hipGraph after `warmup` eager steps and replay it from then on (single process
+        only: an RCCL all-reduce inside a captured graph is not exercised here).  Launch-bound otherwise: ~900 launches
+        of 5-300 us each per step, enqueued from Python."""
+        self._graph = dict(warmup=warmup, seen=0, graph=None)
+
+    def _graph_signature(self, real_imgs, wrong_imgs, txt_embedding, noise, eps):
+        ts = list(real_imgs) + list(wrong_imgs) + [txt_embedding, noise] + ([eps] if eps is not None else [])
+        return tuple((tuple(t.shape), t.dtype) for t in ts) + (ops.ACT_BF16, ops.MATH_PLANES)
+
+    def _capture(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps):
+        st = self._graph
+        dev = noise.device
+        static = dict(real=[t.detach().clone() for t in real_imgs], wrong=[t.detach().clone() for t in wrong_imgs],
+                      emb=txt_embedding.detach().clone().requires_grad_(txt_embedding.requires_grad),
+                      noise=noise.detach().clone(), eps=None if eps is None else eps.detach().clone(),
+                      labels=class_labels_to_device(class_labels, dev).clone())
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            with ops.param_grad_mode(True, False):
+                out = self._train_step(static['real'], static['wrong'], static['emb'], static['labels'], static['noise'],
+                                       static['eps'])
+            outs = [o.detach().reshape(()) for o in out]
+        st.update(graph=graph, static=static, outs=outs, sig=self._graph_signature(real_imgs, wrong_imgs, txt_embedding,
+                                                                                    noise, eps))
+        # the capture itself did not execute anything: replay once so that this call IS a step
+        return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps, fresh=True)
+
+    def _replay(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps, fresh=False):
+        st = self._graph
+        s = st['static']
+
+        def put(dst, src):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src.detach(), non_blocking=True)
+        if not fresh:
+            for d, r in zip(s['real'], real_imgs):
+                put(d, r)
+            for d, r in zip(s['wrong'], wrong_imgs):
+                put(d, r)
+            put(s['emb'], txt_embedding)
+            put(s['noise'], noise)
+            if eps is not None:
+                put(s['eps'], eps)
+            put(s['labels'], class_labels_to_device(class_labels, noise.device))
+        st['graph'].replay()
+        for f in [self.flatG] + self.flatsD:
+            f.step_count += 1
+        if txt_embedding.requires_grad and s['emb'].grad is not None:
+            txt_embedding.grad = s['emb'].grad
+        return tuple(st['outs'])
+
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
+        st = self._graph
+        if st is not None and not self.distributed and torch.cuda.is_available():
+            if st['graph'] is not None:
+                if st['sig'] == self._graph_signature(real_imgs, wrong_imgs, txt_embedding, noise, eps):
+                    return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
+                # another batch shape (ragged last batch of an epoch): eager
+            elif st['seen'] >= st['warmup'] and (eps is not None or st.get('allow_rng', True)):
+                return self._capture(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
+            else:
+                st['seen'] += 1
         # kernels accumulate into the flat gradient buffers (zeroed per update); the switches are scoped to the step, so
         # a later stock-optimiser use of the modules in this process gets autograd-returned gradients again.
         # S2I_WGRAD_STREAM=1 is a rejected experiment (DESIGN.md section 3), slower than the default.

@@ -589,3 +589,50 @@ def test_d_net512_1024_against_reference_golden(gpu, size):
     assert_close_l2(xg.grad[:, :, ::61, ::53], torch.from_numpy(gold['d%d_dx_sample' % size]), 2e-2, what="dx")
     s, a = float(xg.grad.double().sum()), float(xg.grad.double().abs().sum())
     assert abs(a - float(gold['d%d_dx_sum' % size][1])) <= 2e-2 * a, (s, a)
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_hip_graph_replay_matches_eager(gpu, bf16):
+    """The single-GPU step captured in a hipGraph (condGANTrainer.enable_graph) and replayed must be the eager step:
+    five iterations with fresh inputs each (copied into the graph's static buffers), bit-identical parameters, Adam state,
+    EMA, BatchNorm buffers and losses; the gradient w.r.t. the embedding is handed back too."""
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
+    case = dict(CASES['small3'], B=8)
+    batch = make_batch(case)
+    old = ops.ACT_BF16
+    ops.ACT_BF16 = bf16
+    finals = []
+    try:
+        for graphed in (False, True):
+            netG, netsD = build_nets(case)
+            netG.to(gpu)
+            for d in netsD:
+                d.to(gpu)
+            tr = T.condGANTrainer(None, None, 256, False)
+            tr.build(netG, netsD)
+            if graphed:
+                tr.enable_graph(warmup=2)
+            b = to_dev(batch, gpu)
+            gen = torch.Generator(device=gpu).manual_seed(5)
+            losses, gemb = [], None
+            for it in range(5):
+                noise = torch.randn(b['noise'].shape, device=gpu, generator=gen)
+                eps = torch.randn(b['eps'].shape, device=gpu, generator=gen)
+                real = [torch.rand(t.shape, device=gpu, generator=gen) * 2 - 1 for t in b['real']]
+                emb = torch.randn(b['emb'].shape, device=gpu, generator=gen).requires_grad_(True)
+                out = tr.train_step(real, b['wrong'], emb, batch['labels'], noise, eps)
+                losses.append(torch.stack([o.detach().reshape(()) for o in out]).clone())
+                gemb = emb.grad.detach().clone()
+            torch.cuda.synchronize()
+            if graphed:
+                assert tr._graph['graph'] is not None
+            state = [tr.flatG.p.clone(), tr.flatG.m.clone(), tr.flatG.v.clone(), tr.flatG.avg.clone()]
+            state += [f.p.clone() for f in tr.flatsD] + [f.v.clone() for f in tr.flatsD]
+            state += [netsD[2].state_dict()['img_code_s64_2.1.running_var'].clone(),
+                      netG.state_dict()['h_net1.fc.1.num_batches_tracked'].clone(), torch.stack(losses), gemb]
+            finals.append(state)
+    finally:
+        ops.ACT_BF16 = old
+    for a, c in zip(*finals):
+        assert torch.equal(a, c)
+    assert int(finals[1][-3]) == 5
