@@ -40,9 +40,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
-    ap.add_argument("--graph", type=int, default=1,
-                    help="1 (default): capture the single-GPU step in a hipGraph after the first warm-up steps and replay it; "
-                         "0: enqueue every launch from Python")
+    ap.add_argument("--graph", type=int, default=0,
+                    help="1: capture the single-GPU step in a hipGraph after the first warm-up steps and replay it (measured "
+                         "SLOWER on ROCm 7.2: the replay serialises the per-discriminator streams, DESIGN.md); 0 (default): "
+                         "enqueue every launch from Python")
     ap.add_argument("--no-side-leg", action="store_true", help="skip the extra bf16x3 measurement of f32 runs (profiling)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16", "bf16p"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "

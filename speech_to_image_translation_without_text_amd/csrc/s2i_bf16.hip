@@ -20,6 +20,7 @@
 // Rows of the GEMM are output pixels; a block owns a tile of 128 of them shaped TB x TH x TW (powers of two) chosen
 // from the map size, e.g. 4 x 32 pixels of one image on wide maps, 8 whole 4x4 maps at the discriminators' tails.
 #include "s2i_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -49,6 +50,9 @@ struct ConvBP {
   int stats, nparts;
   long long Mrows;         // rows of y (all phases)
   unsigned x_bytes, w_bytes;
+  int dbg;                 // ablation switches of tools/conv16_bench.py (S2I_B16_DBG; 0 in production): 1 no patch loads after
+                           // the first, 2 no weight loads after the first, 4 no LDS staging after the first, 8 no MFMA,
+                           // 16 no output stores
 };
 
 __device__ __forceinline__ u32x4 bload16(__amdgpu_buffer_rsrc_t r, int byte_off) {
@@ -61,11 +65,16 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 
 // KIND: geometry; BN: output channels per block; CK: channels per LDS stage; waves 2x2 (BN >= 64) or 4x1 (BN = 32)
-template <int KIND, int BN, int CK>
+// TG: taps per LDS stage (T / TG stages per channel chunk); PIN: fragment reads software-pipelined one k-step ahead with the
+// order pinned (sched_barrier) instead of left to the compiler
+// DMA: the weight stage goes global -> LDS directly (global_load_lds, 16 bytes per lane, no VGPRs, no ds_write) into one of
+// TWO stage buffers while the matrix loop reads the other: one barrier per stage instead of two.  The LDS image is the same
+// swizzled [row][CK] image; the swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear).
+template <int KIND, int BN, int CK, int TG, bool PIN, int DBG = 0, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   constexpr int T = KIND == KB_K3S1 ? 9 : (KIND == KB_K4S2 ? 16 : 4);
-  constexpr int TG = KIND == KB_K4S2 ? 8 : T;       // taps per LDS stage
   constexpr int NG = T / TG;
+  static_assert(NG * TG == T, "tap groups must tile the taps");
   constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
   constexpr int TM = 128 / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int SEGS = CK / 8;                      // 16-byte segments per LDS row
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch | weight stage], reused by the epilogue
   unsigned char* As = smem;
   unsigned char* Bs = smem + ((p.npix * ROWB + 255) & ~255);
+  constexpr int B_BYTES = TG * BN * ROWB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -105,15 +115,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   // ---- patch staging plan of this thread: global byte offset (chunk 0) and swizzled LDS offset per load ----
   int pgo[NPL], plo[NPL];
   const int nseg = p.npix * SEGS;
+  const float inv_pw = 1.0f / (float)PW, inv_ph = 1.0f / (float)PH;
 #pragma unroll
   for (int q = 0; q < NPL; ++q) {
     const int e = tid + q * 256;
     int go = S2I_OOB, lo = -1;
     if (e < nseg) {
+      // pix < 1024: floor(pix / PW) = (int)((pix + 0.5) * (1 / PW)) exactly in fp32 (no integer-division sequences)
       const int pix = e / SEGS, seg = e & (SEGS - 1);
-      const int xl = pix % PW;
-      const int rest = pix / PW;
-      const int yl = rest % PH, tb = rest / PH;
+      const int rest = (int)(((float)pix + 0.5f) * inv_pw);
+      const int xl = pix - rest * PW;
+      const int tb = (int)(((float)rest + 0.5f) * inv_ph);
+      const int yl = rest - tb * PH;
       const int b = b0 + tb, iy = iy0 + yl, ix = ix0 + xl;
       if (b < p.B && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) go = (((b * p.H + iy) * p.W + ix) * p.C + seg * 8) * 2;
       const int xs = KIND == KB_K4S2 ? (xl & 1) * (PW >> 1) + (xl >> 1) : xl;   // even / odd columns de-interleaved
@@ -135,20 +148,40 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   // (computed on the fly: BN and SEGS are powers of two)
   const int wstage = TG * p.Npad * CK;               // elements per (chunk, tap group)
   u32x4 ra[NPL], rb[NBL];
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunk, c_begin + p.cps);
+  const int s_begin = c_begin * NG, s_end = c_end * NG;
 
   auto fetch = [&](int st, bool with_a) {            // st = chunk * NG + group
     const int cc = st / NG, tg = st - cc * NG;
-    if (with_a) {
+    if (with_a && !((DBG & 1) && st != s_begin)) {
       const int coff = cc * CK * 2;
 #pragma unroll
       for (int q = 0; q < NPL; ++q) ra[q] = bload16(rx, pgo[q] == S2I_OOB ? S2I_OOB : pgo[q] + coff);
     }
     const int wbase = ((phase * p.nchunk + cc) * NG + tg) * wstage + n0 * CK;
+    if ((DBG & 2) && st != s_begin) return;
+    if constexpr (DMA) {
+      unsigned char* dstb = Bs + ((st - s_begin) & 1) * B_BYTES;
 #pragma unroll
-    for (int q = 0; q < NBL; ++q) {
-      const int e = tid + q * 256;
-      const int seg = e & (SEGS - 1), n = (e / SEGS) & (BN - 1), t = e / (SEGS * BN);
-      rb[q] = bload16(rw, e < BSEG ? (wbase + (t * p.Npad + n) * CK + seg * 8) * 2 : S2I_OOB);
+      for (int q = 0; q < NBL; ++q) {
+        if (q * 256 + wave * 64 < BSEG) {            // wave-uniform: a wave-instruction fills 64 consecutive 16-byte slots
+          const int e = tid + q * 256;
+          const int segp = e & (SEGS - 1), row = e / SEGS;          // LDS slot (row, swizzled segment)
+          const int seg = segp ^ ((row >> LGR) & (SEGS - 1));       // ... holds this source segment
+          const int n = row & (BN - 1), t = row / BN;
+          const unsigned short* src = p.w + (wbase + (t * p.Npad + n) * CK + seg * 8);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dstb + (q * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NBL; ++q) {
+        const int e = tid + q * 256;
+        const int seg = e & (SEGS - 1), n = (e / SEGS) & (BN - 1), t = e / (SEGS * BN);
+        rb[q] = bload16(rw, e < BSEG ? (wbase + (t * p.Npad + n) * CK + seg * 8) * 2 : S2I_OOB);
+      }
     }
   };
   auto stage = [&](bool with_a) {
@@ -157,12 +190,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       for (int q = 0; q < NPL; ++q)
         if (plo[q] >= 0) *reinterpret_cast<u32x4*>(As + plo[q]) = ra[q];
     }
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int q = 0; q < NBL; ++q) {
-      const int e = tid + q * 256;
-      if (e < BSEG) {
-        const int seg = e & (SEGS - 1), row = e / SEGS;  // row = t * BN + n
-        *reinterpret_cast<u32x4*>(Bs + row * ROWB + ((seg ^ ((row >> LGR) & (SEGS - 1))) << 4)) = rb[q];
+      for (int q = 0; q < NBL; ++q) {
+        const int e = tid + q * 256;
+        if (e < BSEG) {
+          const int seg = e & (SEGS - 1), row = e / SEGS;  // row = t * BN + n
+          *reinterpret_cast<u32x4*>(Bs + row * ROWB + ((seg ^ ((row >> LGR) & (SEGS - 1))) << 4)) = rb[q];
+        }
       }
     }
   };
@@ -175,16 +210,15 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int c_begin = split * p.cps;
-  const int c_end = min(p.nchunk, c_begin + p.cps);
-  const int s_begin = c_begin * NG, s_end = c_end * NG;
   if (s_begin < s_end) fetch(s_begin, true);
   for (int st = s_begin; st < s_end; ++st) {
     const bool new_a = (st % NG) == 0;
-    stage(new_a);
+    if (!((DBG & 4) && st != s_begin)) stage(new_a);
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this stage's weights have landed in LDS
     __syncthreads();
     if (st + 1 < s_end) fetch(st + 1, ((st + 1) % NG) == 0);
     const int tg = st % NG;
+    const unsigned char* Bcur = DMA ? Bs + ((st - s_begin) & 1) * B_BYTES : Bs;
     // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (two named register sets,
     // order pinned): the LDS latency hides behind this wave's own MFMAs, and no more than two sets are ever live
     auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
@@ -202,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int brow = tl * BN + wn * TN * 32 + j * 32 + l31;
-        b[j] = *reinterpret_cast<const bf16x8*>(Bs + brow * ROWB + (((ks * 2 + lh) ^ ((brow >> LGR) & (SEGS - 1))) << 4));
+        b[j] = *reinterpret_cast<const bf16x8*>(Bcur + brow * ROWB + (((ks * 2 + lh) ^ ((brow >> LGR) & (SEGS - 1))) << 4));
       }
     };
     auto mma = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
@@ -210,23 +244,35 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          if constexpr (!(DBG & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          else asm volatile("" :: "v"(a[i]), "v"(b[j]));  // keeps the fragment reads alive
     };
     constexpr int NS = TG * KS;
-    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-    ldfr(0, a0, b0);
+    if constexpr (PIN) {
+      bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+      ldfr(0, a0, b0);
 #pragma unroll
-    for (int s2 = 0; s2 < NS; s2 += 2) {
-      if (s2 + 1 < NS) ldfr(s2 + 1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (s2 + 1 < NS) mma(a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int s2 = 0; s2 < NS; s2 += 2) {
+        if (s2 + 1 < NS) ldfr(s2 + 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2 + 1 < NS) mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        bf16x8 a0[TM], b0[TN];
+        ldfr(s2, a0, b0);
+        mma(a0, b0);
+      }
     }
-    __syncthreads();
+    // DMA: the other weight buffer is refilled only after the next leading barrier, so the trailing barrier is needed
+    // only where the (single) patch buffer is about to be overwritten, and before the epilogue reuses LDS
+    if (!DMA || st + 1 >= s_end || ((st + 1) % NG) == 0) __syncthreads();
   }
 
   // ---- epilogue ----
@@ -301,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       const int rr = e / SPR, sg = e & (SPR - 1);
       const long long row = out_row(rr);
       const int n = n0 + sg * 8;
-      if (row >= 0 && n < p.N)
+      if (row >= 0 && n < p.N && !(DBG & 16))
         *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
     }
   }
@@ -450,7 +496,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 
 // ---- host-side planning ------------------------------------------------------------------------------------------
 struct BPlan {
-  int kb, T, NG, Ho, Wo, nphases, BN, CK, Npad;
+  int kb, T, NG, TG, pin, dma, Ho, Wo, nphases, BN, CK, Npad;
   int lgTW, lgTH, lgTB, tilesX, tilesY, tilesB, PH, PW, npix;
   int nchunk, splitk, cps, gridM, gridN;
   long long Mrows;
@@ -472,7 +518,19 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
     case S2I_TCONV_K4S2: pl->kb = KB_TCONV; pl->T = 4; pl->NG = 1; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
     default: S2I_FAIL("conv(bf16): unsupported kind %d", d->kind);
   }
+  // experiment switch: 0 = all taps of a chunk per stage (8 for the 4x4), pinned; 1 = a third / quarter / half of them,
+  // pinned; 2 = the same, compiler-scheduled
+  static const int variant = getenv("S2I_B16_VARIANT") ? atoi(getenv("S2I_B16_VARIANT")) : 0;
   pl->BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
+  pl->TG = pl->kb == KB_K4S2 ? 8 : pl->T;
+  pl->pin = 1;
+  pl->dma = 0;
+  if (variant && pl->BN == 128) {
+    pl->TG = pl->kb == KB_K3S1 ? 3 : (pl->kb == KB_K4S2 ? 4 : 2);
+    pl->pin = variant != 2;
+    pl->dma = variant == 3;
+  }
+  pl->NG = pl->T / pl->TG;
   int ck = (pl->kb == KB_TCONV ? 4096 : 2048) / pl->BN;
   if (ck > (pl->kb == KB_K4S2 ? 32 : 64)) ck = pl->kb == KB_K4S2 ? 32 : 64;  // the stride-2 patch is 5 pixels per output pixel
   while (ck > 16 && (d->Cx % ck) != 0) ck >>= 1;
@@ -528,9 +586,9 @@ int bf16_stat_parts(const BPlan& pl, int groups) {
 }
 
 size_t bf16_smem_bytes(const BPlan& pl) {
-  const int rowb = pl.CK * 2, tg = pl.kb == KB_K4S2 ? 8 : pl.T;
+  const int rowb = pl.CK * 2, tg = pl.TG;
   const size_t ab = ((size_t)pl.npix * rowb + 255) & ~(size_t)255;
-  const size_t main_b = ab + (size_t)tg * pl.BN * rowb;
+  const size_t main_b = ab + (size_t)tg * pl.BN * rowb * (pl.dma ? 2 : 1);
   const size_t epi = (size_t)128 * (pl.BN * 2 + 16);
   return main_b > epi ? main_b : epi;
 }
@@ -541,28 +599,44 @@ bool bf16_has_kernel(int kb, int bn, int ck) {
   return (bn == 128 && ck == 16) || (bn == 64 && ck == 32) || (bn == 32 && (ck == 64 || ck == 32));
 }
 
-template <int KIND, int BN, int CK>
+template <int KIND, int BN, int CK, int TG, bool PIN, bool DMA = false>
 int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   const size_t shb = bf16_smem_bytes(pl);
   static bool raised = false;  // > 64 KB of dynamic LDS needs the attribute once per kernel
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<KIND, BN, CK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       96 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<KIND, BN, CK, TG, PIN, 0, DMA>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) S2I_FAIL("conv(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
     raised = true;
   }
-  hipLaunchKernelGGL((conv_bf16_kernel<KIND, BN, CK>), grid, dim3(256), shb, st, p);
+  hipLaunchKernelGGL((conv_bf16_kernel<KIND, BN, CK, TG, PIN, 0, DMA>), grid, dim3(256), shb, st, p);
   return 0;
 }
 
 int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
-  const int kb = pl.kb, bn = pl.BN, ck = pl.CK;
-#define S2I_CASE(K, bn_, ck_) if (kb == K && bn == bn_ && ck == ck_) return launch_one<K, bn_, ck_>(pl, p, grid, st);
-  S2I_CASE(KB_K3S1, 128, 16) S2I_CASE(KB_K3S1, 64, 32) S2I_CASE(KB_K3S1, 32, 64) S2I_CASE(KB_K3S1, 32, 32)
-  S2I_CASE(KB_K4S2, 128, 16) S2I_CASE(KB_K4S2, 64, 32) S2I_CASE(KB_K4S2, 32, 32)
-  S2I_CASE(KB_TCONV, 128, 32) S2I_CASE(KB_TCONV, 64, 64) S2I_CASE(KB_TCONV, 32, 64) S2I_CASE(KB_TCONV, 32, 32)
+  const int kb = pl.kb, bn = pl.BN, ck = pl.CK, tg = pl.TG, pin = pl.pin;
+  if (pl.dma) {
+    if (kb == KB_K3S1 && bn == 128 && ck == 16 && tg == 3) return launch_one<KB_K3S1, 128, 16, 3, true, true>(pl, p, grid, st);
+    if (kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 4) return launch_one<KB_K4S2, 128, 16, 4, true, true>(pl, p, grid, st);
+    if (kb == KB_TCONV && bn == 128 && ck == 32 && tg == 2) return launch_one<KB_TCONV, 128, 32, 2, true, true>(pl, p, grid, st);
+    S2I_FAIL("conv(bf16): no DMA kernel for kind %d BN=%d CK=%d TG=%d", kb, bn, ck, tg);
+  }
+#define S2I_CASE(K, bn_, ck_, tg_, pin_) \
+  if (kb == K && bn == bn_ && ck == ck_ && tg == tg_ && pin == pin_) return launch_one<K, bn_, ck_, tg_, pin_>(pl, p, grid, st);
+  if (p.dbg && kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 8 && pin) {
+    const size_t shb = bf16_smem_bytes(pl);
+#define S2I_DBG(v) if (p.dbg == v) { hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>), grid, dim3(256), shb, st, p); return 0; }
+    S2I_DBG(1) S2I_DBG(2) S2I_DBG(4) S2I_DBG(7) S2I_DBG(8) S2I_DBG(15) S2I_DBG(16) S2I_DBG(31) S2I_DBG(24)
+#undef S2I_DBG
+  }
+  S2I_CASE(KB_K3S1, 128, 16, 9, true) S2I_CASE(KB_K3S1, 128, 16, 3, true) S2I_CASE(KB_K3S1, 128, 16, 3, false)
+  S2I_CASE(KB_K3S1, 64, 32, 9, true) S2I_CASE(KB_K3S1, 32, 64, 9, true) S2I_CASE(KB_K3S1, 32, 32, 9, true)
+  S2I_CASE(KB_K4S2, 128, 16, 8, true) S2I_CASE(KB_K4S2, 128, 16, 4, true) S2I_CASE(KB_K4S2, 128, 16, 4, false)
+  S2I_CASE(KB_K4S2, 64, 32, 8, true) S2I_CASE(KB_K4S2, 32, 32, 8, true)
+  S2I_CASE(KB_TCONV, 128, 32, 4, true) S2I_CASE(KB_TCONV, 128, 32, 2, true) S2I_CASE(KB_TCONV, 128, 32, 2, false)
+  S2I_CASE(KB_TCONV, 64, 64, 4, true) S2I_CASE(KB_TCONV, 32, 64, 4, true) S2I_CASE(KB_TCONV, 32, 32, 4, true)
 #undef S2I_CASE
-  S2I_FAIL("conv(bf16): no kernel for kind %d BN=%d CK=%d", kb, bn, ck);
+  S2I_FAIL("conv(bf16): no kernel for kind %d BN=%d CK=%d TG=%d", kb, bn, ck, tg);
 }
 
 }  // namespace
@@ -632,6 +706,8 @@ extern "C" int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned shor
   const unsigned long long wb = (unsigned long long)pl.nphases * pl.T * pl.Npad * d->Cx * 2ull;
   S2I_REQUIRE(xb < 0x7ff00000ull && wb < 0x7ff00000ull, "conv(bf16): tensor exceeds the 2 GiB buffer-addressing window");
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
+  static const int dbg = getenv("S2I_B16_DBG") ? atoi(getenv("S2I_B16_DBG")) : 0;
+  p.dbg = dbg;
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   if (launch_conv_bf16(pl, p, grid, ST)) return 1;
   S2I_LAUNCH_CHECK("conv_bf16");

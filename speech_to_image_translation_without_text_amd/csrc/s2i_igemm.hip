@@ -779,52 +779,66 @@ __global__ __launch_bounds__(256) void small_n_conv_kernel(IgemmP p) {
   }
   __syncthreads();
   const int q = lane % LPP, pl = lane / LPP;
-  const int m = (blockIdx.x * 4 + wave) * PPW + pl;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  int b = 0, oy = 0, ox = 0;
-  if (m < p.M) {
-    b = m >> p.lgHoWo;
-    const int r = m & ((1 << p.lgHoWo) - 1);
-    oy = r >> p.lgWo;
-    ox = r & (p.Wo - 1);
-    const int by = oy * s - pad, bx = ox * s - pad;
-    const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
-    const long long xo = (((long long)b * p.H + by) * p.W + bx) * p.Cx + q * 4;
-    for (int t = 0; t < p.T; ++t) {
-      if (!((mask >> t) & 1u)) continue;
-      int dy, dx;
-      tap_delta(p.kind, kw, t, py, px, dy, dx);
-      const long long xe = xo + ((long long)dy * p.W + dx) * p.Cx;
-      f32x4 xv;
-      if (p.x16) {
-        const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
-        xv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
-                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
-      } else {
-        xv = *reinterpret_cast<const f32x4*>(p.x + xe);
+  // grid-stride over groups of PPW pixels per wave: the weight table above is staged once per block, not once per 4 * PPW
+  // pixels (the one-group-per-wave form ran the D_NET256 image gradient at 0.2 TB/s)
+  const int ngroups = (p.M + PPW - 1) / PPW;
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int m = grp * PPW + pl;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int b = 0, oy = 0, ox = 0;
+    if (m < p.M) {
+      b = m >> p.lgHoWo;
+      const int r = m & ((1 << p.lgHoWo) - 1);
+      oy = r >> p.lgWo;
+      ox = r & (p.Wo - 1);
+      const int by = oy * s - pad, bx = ox * s - pad;
+      const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
+      const long long xo = (((long long)b * p.H + by) * p.W + bx) * p.Cx + q * 4;
+      for (int t = 0; t < p.T; ++t) {
+        if (!((mask >> t) & 1u)) continue;
+        int dy, dx;
+        tap_delta(p.kind, kw, t, py, px, dy, dx);
+        const long long xe = xo + ((long long)dy * p.W + dx) * p.Cx;
+        f32x4 xv;
+        if (p.x16) {
+          const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+          xv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                     __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+        } else {
+          xv = *reinterpret_cast<const f32x4*>(p.x + xe);
+        }
+        const float* wp = wl + ((size_t)t * p.Ca + q * 4) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc += xv[j] * *reinterpret_cast<const f32x4*>(wp + j * 4);
       }
-      const float* wp = wl + ((size_t)t * p.Ca + q * 4) * 4;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc += xv[j] * *reinterpret_cast<const f32x4*>(wp + j * 4);
     }
-  }
 #pragma unroll
-  for (int sft = 1; sft < LPP; sft <<= 1)
+    for (int sft = 1; sft < LPP; sft <<= 1)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], sft);
-  if (q == 0 && m < p.M) {
-    long long row = m;
-    if (p.kind == S2I_TCONV_K4S2) row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      for (int n = 0; n < 4; ++n) acc[n] += __shfl_xor(acc[n], sft);
+    if (q == 0 && m < p.M) {
+      long long row = m;
+      if (p.kind == S2I_TCONV_K4S2) row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      f32x4 o;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      if (n >= p.N) break;
-      float v = acc[n];
-      if (p.bias) v += p.bias[n];
-      if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
-      else if (p.act == S2I_ACT_TANH) v = tanhf(v);
-      else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
-      if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(v);
-      else p.y[row * p.ldy + n] = v;
+      for (int n = 0; n < 4; ++n) {
+        float v = acc[n];
+        if (p.bias && n < p.N) v += p.bias[n];
+        if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+        else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+        o[n] = v;
+      }
+      if (p.N == 4 && !p.y16 && (p.ldy & 3) == 0) {
+        *reinterpret_cast<f32x4*>(p.y + row * p.ldy) = o;
+      } else {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (n >= p.N) break;
+          if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(o[n]);
+          else p.y[row * p.ldy + n] = o[n];
+        }
+      }
     }
   }
 }
@@ -1931,7 +1945,9 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     // HBM-bound RGB-sized layers: VALU kernel instead of a 32-wide MFMA tile that is 7/8 padding
     p.wt = d->wmode != 0;
     const int lpp = pl.Ca / 4, ppw = 64 / lpp;
-    dim3 sgrid(s2i_cdiv(pl.M, 4 * ppw), 1, pl.nphases);
+    int sblocks = s2i_cdiv(pl.M, 4 * ppw);
+    if (sblocks > 2048 / pl.nphases) sblocks = 2048 / pl.nphases;   // 8 blocks per CU; the kernel strides over the rest
+    dim3 sgrid(sblocks, 1, pl.nphases);
     const size_t shb = (size_t)pl.T * pl.Ca * 4 * sizeof(float);
     if (lpp == 4) hipLaunchKernelGGL((small_n_conv_kernel<4>), sgrid, dim3(256), shb, st, p);
     else if (lpp == 8) hipLaunchKernelGGL((small_n_conv_kernel<8>), sgrid, dim3(256), shb, st, p);

@@ -461,7 +461,9 @@ class condGANTrainer(object):
         """Capture the train step in a hipGraph after `warmup` eager steps and replay it from then on (single process
         only: an RCCL all-reduce inside a captured graph is not exercised here).  Launch-bound otherwise: ~900 launches
         of 5-300 us each per step, enqueued from Python."""
-        self._graph = dict(warmup=warmup, seen=0, graph=None)
+        # warm-up and capture run on one private stream: autograd's AccumulateGrad nodes remember the stream they were
+        # created on, and one that lives on the (non-capturing) default stream invalidates the capture
+        self._graph = dict(warmup=warmup, seen=0, graph=None, stream=torch.cuda.Stream())
 
     def _graph_signature(self, real_imgs, wrong_imgs, txt_embedding, noise, eps):
         ts = list(real_imgs) + list(wrong_imgs) + [txt_embedding, noise] + ([eps] if eps is not None else [])
@@ -474,13 +476,19 @@ class condGANTrainer(object):
                       emb=txt_embedding.detach().clone().requires_grad_(txt_embedding.requires_grad),
                       noise=noise.detach().clone(), eps=None if eps is None else eps.detach().clone(),
                       labels=class_labels_to_device(class_labels, dev).clone())
+        # no autograd graph of an earlier iteration may survive into the capture (it would keep its AccumulateGrad nodes)
+        self.fake_imgs = self.mu = self.logvar = self._stacked_logits = None
+        self.real_imgs = self.wrong_imgs = self.txt_embedding = None
+        import gc
+        gc.collect()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, stream=st['stream']):
             with ops.param_grad_mode(True, False):
                 out = self._train_step(static['real'], static['wrong'], static['emb'], static['labels'], static['noise'],
                                        static['eps'])
             outs = [o.detach().reshape(()) for o in out]
+        del out
         st.update(graph=graph, static=static, outs=outs, sig=self._graph_signature(real_imgs, wrong_imgs, txt_embedding,
                                                                                     noise, eps))
         # the capture itself did not execute anything: replay once so that this call IS a step
@@ -492,7 +500,8 @@ class condGANTrainer(object):
 
         def put(dst, src):
             if dst.data_ptr() != src.data_ptr():
-                dst.copy_(src.detach(), non_blocking=True)
+                with torch.no_grad():
+                    dst.copy_(src.detach(), non_blocking=True)
         if not fresh:
             for d, r in zip(s['real'], real_imgs):
                 put(d, r)
@@ -517,10 +526,17 @@ class condGANTrainer(object):
                 if st['sig'] == self._graph_signature(real_imgs, wrong_imgs, txt_embedding, noise, eps):
                     return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
                 # another batch shape (ragged last batch of an epoch): eager
-            elif st['seen'] >= st['warmup'] and (eps is not None or st.get('allow_rng', True)):
+            elif st['seen'] >= st['warmup']:
                 return self._capture(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
             else:
                 st['seen'] += 1
+                gs, cur = st['stream'], torch.cuda.current_stream()
+                gs.wait_stream(cur)
+                with torch.cuda.stream(gs), ops.param_grad_mode(
+                        True, self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"):
+                    out = self._train_step(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
+                cur.wait_stream(gs)
+                return out
         # kernels accumulate into the flat gradient buffers (zeroed per update); the switches are scoped to the step, so
         # a later stock-optimiser use of the modules in this process gets autograd-returned gradients again.
         # S2I_WGRAD_STREAM=1 is a rejected experiment, slower than the default.
