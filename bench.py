@@ -111,7 +111,8 @@ def bf16_kernel_roofline(dev, B):
             "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
             "frac_profiled": round(abytes / (prof["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4) if prof.get("avg_ns") else None,
             "profiled_source": prof.get("avg_source"),
-            "kernel": "conv_bf16_kernel<K4S2,128,16> (v_mfma_f32_32x32x16_bf16, LDS-staged 10x66-pixel input patch)",
+            "kernel": "conv_bf16_kernel<K4S2, BN 128, CK 32, 4 taps per stage> (v_mfma_f32_32x32x16_bf16, LDS-staged 10x66-pixel "
+                      "input patch)",
             "algorithmic_bytes": abytes,
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (ms * 1e-3) / 2.5e15, 4),
             "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) bf16 NHWC, %.1f MB algorithmic, %.2f GFLOP, %.3f ms"
@@ -207,6 +208,53 @@ def cpu_baseline(B):
     return {"value": round(iters * B / dt, 3), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d full train iterations (G fwd, 3 D updates, G update, EMA), branch_num=3, batch %d, "
                       "torch %s CPU fp32, %.1f s" % (iters, B, torch.__version__, dt)}
+
+
+def bf16_side_leg(dev, args, model, ops, T, cfg, B=48):
+    """One more measurement in the same process: the step in bf16 activation mode at batch 48 (BASELINE config 4)."""
+    ops.ACT_BF16 = True
+    cfg.TRAIN.BATCH_SIZE = B
+    torch.manual_seed(0)
+    netG = model.G_NET()
+    netG.apply(T.weights_init)
+    netsD = []
+    for cls in (model.D_NET64, model.D_NET128, model.D_NET256):
+        d = cls()
+        d.apply(T.weights_init)
+        netsD.append(d)
+    netG.to(dev)
+    for d in netsD:
+        d.to(dev)
+    tr = T.condGANTrainer(None, None, 256, False, local_rank=dev.index or 0, distributed=False)
+    tr.build(netG, netsD)
+    batch, gen = synthetic_batch(B, dev, 1)
+    noise = torch.empty(B, cfg.GAN.Z_DIM, device=dev)
+    eps = torch.empty(B, cfg.GAN.EMBEDDING_DIM, device=dev)
+
+    def step():
+        noise.normal_(generator=gen)
+        eps.normal_(generator=gen)
+        return tr.train_step(batch["real"], batch["wrong"], batch["emb"].detach().requires_grad_(True), batch["labels"], noise,
+                             eps)
+    for _ in range(3):
+        out = step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    losses = [float(v.detach()) for v in out]
+    ms = el / args.steps * 1e3
+    step_bytes = (836.6e6 * B + 4852.7e6) * 0.5 + 3277.9e6 + 254.9e6
+    res = {"value": round(B * args.steps / el, 2), "unit": "images/sec", "ms_per_step": round(ms, 3), "batch": B,
+           "dtype": "bf16", "note": MATH_NOTE["bf16"],
+           "step_hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+           "losses": {"errD_total": losses[0], "errG_total": losses[1], "kl": losses[2]},
+           "roofline": bf16_kernel_roofline(dev, B)}
+    del tr, netG, netsD
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -378,6 +426,16 @@ def main():
                     line["bf16x3_split"] = {"error": str(e)[:200]}
                 finally:
                     ops.MATH_PLANES = 0
+            if args.math == "f32" and not args.no_side_leg:
+                # BASELINE config 4 (bf16 activations / weights, batch 48 per GPU) beside the headline fp32 value: its own
+                # networks, trainer and roofline object; never the value
+                try:
+                    line["bf16_config4"] = bf16_side_leg(dev, args, model, ops, T, cfg)
+                except Exception as e:  # noqa: BLE001
+                    line["bf16_config4"] = {"error": str(e)[:200]}
+                finally:
+                    ops.ACT_BF16 = False
+                    cfg.TRAIN.BATCH_SIZE = B
             if not args.no_cpu_baseline:
                 note("timing the CPU oracle (bounded sample, batch %d)" % args.cpu_baseline_batch)
                 line["cpu_baseline"] = cpu_baseline(args.cpu_baseline_batch)

@@ -518,21 +518,28 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
     case S2I_TCONV_K4S2: pl->kb = KB_TCONV; pl->T = 4; pl->NG = 1; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
     default: S2I_FAIL("conv(bf16): unsupported kind %d", d->kind);
   }
-  // experiment switch: 0 = all taps of a chunk per stage (8 for the 4x4), pinned; 1 = a third / quarter / half of them,
-  // pinned; 2 = the same, compiler-scheduled
+  // Stage shape.  Default: all 9 taps of a 3x3 / the 4 taps of a transposed-conv phase per stage; the stride-2 4x4 conv
+  // with BN = 128 takes 4 taps x 32 channels (64-byte pieces of a pixel instead of 32-byte ones: measured -10 % time, the
+  // 32-byte pieces left half of every 64-byte memory request unused).  S2I_B16_VARIANT (experiments, tools/conv16_bench.py;
+  // none changed the time by more than 5 %): 1 = a third / quarter / half of the taps per stage (3 blocks per CU),
+  // 2 = the same with compiler-scheduled fragment reads, 3 = weights by LDS-DMA into two buffers, one barrier per stage,
+  // 5 = the round's first shape (8 taps x 16 channels) for the 4x4.
   static const int variant = getenv("S2I_B16_VARIANT") ? atoi(getenv("S2I_B16_VARIANT")) : 0;
   pl->BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
   pl->TG = pl->kb == KB_K4S2 ? 8 : pl->T;
   pl->pin = 1;
   pl->dma = 0;
-  if (variant && pl->BN == 128) {
+  if (variant >= 1 && variant <= 3 && pl->BN == 128) {
     pl->TG = pl->kb == KB_K3S1 ? 3 : (pl->kb == KB_K4S2 ? 4 : 2);
     pl->pin = variant != 2;
     pl->dma = variant == 3;
   }
+  const bool wide_ck = variant != 5 && !(variant >= 1 && variant <= 3) && pl->BN == 128 && pl->kb == KB_K4S2;
+  if (wide_ck) pl->TG = 4;
   pl->NG = pl->T / pl->TG;
   int ck = (pl->kb == KB_TCONV ? 4096 : 2048) / pl->BN;
   if (ck > (pl->kb == KB_K4S2 ? 32 : 64)) ck = pl->kb == KB_K4S2 ? 32 : 64;  // the stride-2 patch is 5 pixels per output pixel
+  if (wide_ck) ck = 32;
   while (ck > 16 && (d->Cx % ck) != 0) ck >>= 1;
   if (pl->BN == 32 && ck < 32) ck = 32;
   S2I_REQUIRE((d->Cx % ck) == 0, "conv(bf16): %d channels do not split into chunks of %d", d->Cx, ck);
@@ -549,6 +556,7 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
   else if (pl->kb == KB_K4S2) { pl->PH = 2 * th + 2; pl->PW = 2 * tw + 2; }
   else { pl->PH = th + 1; pl->PW = tw + 1; }
   pl->npix = tb * pl->PH * pl->PW;
+  if (wide_ck && pl->npix > 672 && ck == 32) { pl->CK = ck = 16; pl->TG = 8; pl->NG = 2; }   // 8 maps of 4x4 outputs per tile
   S2I_REQUIRE(pl->npix <= (pl->kb == KB_K4S2 ? (ck == 16 ? 800 : 672) : 320),
               "conv(bf16): patch of %d pixels exceeds the LDS plan", pl->npix);
   pl->gridM = pl->tilesX * pl->tilesY * pl->tilesB;
@@ -595,8 +603,8 @@ size_t bf16_smem_bytes(const BPlan& pl) {
 
 bool bf16_has_kernel(int kb, int bn, int ck) {
   if (kb == KB_TCONV) return (bn == 128 && ck == 32) || (bn == 64 && ck == 64) || (bn == 32 && (ck == 64 || ck == 32));
-  if (kb == KB_K4S2) return (bn == 128 && ck == 16) || (bn == 64 && ck == 32) || (bn == 32 && ck == 32);
-  return (bn == 128 && ck == 16) || (bn == 64 && ck == 32) || (bn == 32 && (ck == 64 || ck == 32));
+  if (kb == KB_K4S2) return (bn == 128 && (ck == 16 || ck == 32)) || (bn == 64 && ck == 32) || (bn == 32 && ck == 32);
+  return (bn == 128 && (ck == 16 || ck == 32)) || (bn == 64 && ck == 32) || (bn == 32 && (ck == 64 || ck == 32));
 }
 
 template <int KIND, int BN, int CK, int TG, bool PIN, bool DMA = false>
@@ -629,6 +637,7 @@ int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st
     S2I_DBG(1) S2I_DBG(2) S2I_DBG(4) S2I_DBG(7) S2I_DBG(8) S2I_DBG(15) S2I_DBG(16) S2I_DBG(31) S2I_DBG(24)
 #undef S2I_DBG
   }
+  S2I_CASE(KB_K3S1, 128, 32, 3, true) S2I_CASE(KB_K4S2, 128, 32, 4, true)
   S2I_CASE(KB_K3S1, 128, 16, 9, true) S2I_CASE(KB_K3S1, 128, 16, 3, true) S2I_CASE(KB_K3S1, 128, 16, 3, false)
   S2I_CASE(KB_K3S1, 64, 32, 9, true) S2I_CASE(KB_K3S1, 32, 64, 9, true) S2I_CASE(KB_K3S1, 32, 32, 9, true)
   S2I_CASE(KB_K4S2, 128, 16, 8, true) S2I_CASE(KB_K4S2, 128, 16, 4, true) S2I_CASE(KB_K4S2, 128, 16, 4, false)
