@@ -134,94 +134,118 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
   }
 }
 
-// reduce [2][G*ppg][C] partials in double; 1024 threads: qpb quads x (1024/qpb) part lanes.  The G groups
-// (independent BatchNorm batches sharing one set of parameters) are processed in order, so the running
-// statistics see G successive momentum updates exactly as G separate forwards would give.
+// Reduce [2][G*ppg][C] partials in double.  Threads = qpb channel quads x `lanes` row lanes (tid = pl * qpb + ql); the G
+// groups (independent BatchNorm batches sharing one set of parameters) own contiguous ranges of `lpg` row lanes and are
+// reduced AT THE SAME TIME: per-lane sums, a shuffle reduction inside each wave over the lanes of equal quad (no barrier),
+// one LDS exchange between waves, then one thread per quad walks the groups in order -- so the running statistics see G
+// successive momentum updates exactly as G separate forwards would give.  (The earlier form ran a 10-level LDS tree with
+// a barrier per level, once per group: 17 us for what is a few hundred KB.)
 template <int MODE>  // 0: BN forward statistics   1: BN backward sums
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int ppg, int G, int C,
                                                            double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ rmean,
                                                            float* __restrict__ rvar, float momentum, float eps,
                                                            float* __restrict__ out, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate, int qpb,
+                                                           float* __restrict__ dbeta, int accumulate, int qpb, int lpg,
                                                            long long* __restrict__ nbt) {
-  extern __shared__ double shd[];  // [2][blockDim.x][4]
+  extern __shared__ double shd[];  // [waves][qpb][8] partial sums, then [G][qpb][8] group sums
   if (MODE == 0 && nbt && blockIdx.x == 0 && threadIdx.x == 0) nbt[0] += G;  // num_batches_tracked
   const int tid = threadIdx.x;
   const int NT = blockDim.x;
-  const int lanes = NT / qpb;
   const int ql = tid % qpb, pl = tid / qpb;
   const int quad = blockIdx.x * qpb + ql;
   const int Q = C / 4;
   const int nparts = ppg * G;
-  double g0[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0};  // sums over groups (backward: dbeta, dgamma)
-  for (int grp = 0; grp < G; ++grp) {
-    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-    if (quad < Q) {
-      for (int pi = grp * ppg + pl; pi < (grp + 1) * ppg; pi += lanes) {
-        const f32x4 v0 = ld4(part + ((size_t)0 * nparts + pi) * C + quad * 4);
-        const f32x4 v1 = ld4(part + ((size_t)1 * nparts + pi) * C + quad * 4);
+  const int grp = pl / lpg, pin = pl - grp * lpg;   // this lane's group and its lane index inside the group
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (quad < Q && grp < G) {
+    for (int pi = grp * ppg + pin; pi < (grp + 1) * ppg; pi += lpg) {
+      const f32x4 v0 = ld4(part + ((size_t)0 * nparts + pi) * C + quad * 4);
+      const f32x4 v1 = ld4(part + ((size_t)1 * nparts + pi) * C + quad * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a0[j] += v0[j]; a1[j] += v1[j]; }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      shd[(0 * NT + tid) * 4 + j] = a0[j];
-      shd[(1 * NT + tid) * 4 + j] = a1[j];
-    }
-    __syncthreads();
-    // tree over the part lanes (thread tid = pl * qpb + ql; lanes is a power of two)
-    for (int sft = lanes >> 1; sft > 0; sft >>= 1) {
-      if (pl < sft) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          shd[(0 * NT + tid) * 4 + j] += shd[(0 * NT + tid + sft * qpb) * 4 + j];
-          shd[(1 * NT + tid) * 4 + j] += shd[(1 * NT + tid + sft * qpb) * 4 + j];
-        }
-      }
-      __syncthreads();
-    }
-    if (pl == 0 && quad < Q) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a0[j] = shd[(0 * NT + tid) * 4 + j];
-        a1[j] = shd[(1 * NT + tid) * 4 + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = quad * 4 + j;
-        if (MODE == 0) {
-          float* o = out + (size_t)grp * 4 * C;
-          const double mean = a0[j] / count;
-          double var = a1[j] / count - mean * mean;
-          if (var < 0) var = 0;
-          const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-          const float sc = gamma[c] * invstd;
-          o[c] = (float)mean;
-          o[C + c] = invstd;
-          o[2 * C + c] = sc;
-          o[3 * C + c] = beta[c] - (float)mean * sc;
-          if (rmean) {
-            const double unb = count > 1 ? var * count / (count - 1) : var;
-            rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-          }
-        } else {
-          float* o = out + (size_t)grp * 2 * C;
-          o[c] = (float)(a0[j] / count);
-          o[C + c] = (float)(a1[j] / count);
-          g0[j] += a0[j];
-          g1[j] += a1[j];
-        }
-      }
+      for (int j = 0; j < 4; ++j) { a[j] += v0[j]; a[4 + j] += v1[j]; }
     }
   }
-  if (MODE == 1 && pl == 0 && quad < Q) {
+  // lanes of one wave that share the quad AND the group: xor offsets qpb .. 32 stay inside a group when lpg * qpb >= 64
+  // (a group then covers whole waves); smaller blocks take the LDS path only
+  const int wave = tid >> 6, lane = tid & 63, nwaves = (NT + 63) >> 6;
+  const bool whole_waves = (lpg * qpb) % 64 == 0;
+  if (whole_waves) {
+    for (int off = 32; off >= qpb; off >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += __shfl_xor(a[j], off);
+    }
+    if (lane < qpb) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) shd[((size_t)wave * qpb + lane) * 8 + j] = a[j];
+    }
+  } else {
+    // few threads per group inside one wave: every lane publishes, the group leader sums
+#pragma unroll
+    for (int j = 0; j < 8; ++j) shd[(size_t)tid * 8 + j] = a[j];
+  }
+  __syncthreads();
+  // group sums -> shd2[g][ql][8] (kept in registers of the group's first lane, then exchanged)
+  double gs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pin == 0 && grp < G && quad < Q) {
+    if (whole_waves) {
+      const int w0 = (grp * lpg * qpb) >> 6, w1 = (((grp + 1) * lpg * qpb) + 63) >> 6;
+      for (int w = w0; w < w1 && w < nwaves; ++w)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gs[j] += shd[((size_t)w * qpb + ql) * 8 + j];
+    } else {
+      for (int k = 0; k < lpg; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gs[j] += shd[((size_t)((grp * lpg + k) * qpb + ql)) * 8 + j];
+    }
+  }
+  __syncthreads();
+  if (pin == 0 && grp < G && quad < Q) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) shd[((size_t)grp * qpb + ql) * 8 + j] = gs[j];
+  }
+  __syncthreads();
+  if (pl != 0 || quad >= Q) return;
+  double g0[4] = {0, 0, 0, 0}, g1[4] = {0, 0, 0, 0};  // sums over groups (backward: dbeta, dgamma)
+  float rm[4] = {0.f, 0.f, 0.f, 0.f}, rv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (MODE == 0 && rmean) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { rm[j] = rmean[quad * 4 + j]; rv[j] = rvar[quad * 4 + j]; }
+  }
+  for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = quad * 4 + j;
+      const double a0 = shd[((size_t)g * qpb + ql) * 8 + j], a1 = shd[((size_t)g * qpb + ql) * 8 + 4 + j];
+      if (MODE == 0) {
+        float* o = out + (size_t)g * 4 * C;
+        const double mean = a0 / count;
+        double var = a1 / count - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        o[c] = (float)mean;
+        o[C + c] = invstd;
+        o[2 * C + c] = sc;
+        o[3 * C + c] = beta[c] - (float)mean * sc;
+        const double unb = count > 1 ? var * count / (count - 1) : var;
+        rm[j] = (1.f - momentum) * rm[j] + momentum * (float)mean;
+        rv[j] = (1.f - momentum) * rv[j] + momentum * (float)unb;
+      } else {
+        float* o = out + (size_t)g * 2 * C;
+        o[c] = (float)(a0 / count);
+        o[C + c] = (float)(a1 / count);
+        g0[j] += a0;
+        g1[j] += a1;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = quad * 4 + j;
+    if (MODE == 0) {
+      if (rmean) { rmean[c] = rm[j]; rvar[c] = rv[j]; }
+    } else {
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)g0[j] : (float)g0[j];
       if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)g1[j] : (float)g1[j];
     }
@@ -1084,17 +1108,22 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
   int qpb = 1;
   while (qpb < 32 && qpb * 32 < Q) qpb <<= 1;
   const int grid = (Q + qpb - 1) / qpb;
-  // part lanes: no more than the list is long (power of two), at most 1024 threads per block
-  int lanes = 1;
-  while (lanes < ppg && lanes * qpb < 1024) lanes <<= 1;
-  const int nthreads = qpb * lanes;
-  const size_t shbytes = (size_t)2 * nthreads * 4 * sizeof(double);
+  // row lanes per group: a power of two, no more than the list is long, groups side by side in at most 1024 threads
+  int lpg = 1;
+  while (lpg < ppg && lpg * 2 * groups * qpb <= 1024) lpg <<= 1;
+  int nthreads = qpb * lpg * groups;
+  nthreads = (nthreads + 63) & ~63;
+  if (nthreads > 1024) nthreads = 1024;
+  const int nwaves = nthreads / 64;
+  size_t slots = (size_t)nthreads > (size_t)nwaves * qpb ? (size_t)nthreads : (size_t)nwaves * qpb;
+  if (slots < (size_t)groups * qpb) slots = (size_t)groups * qpb;
+  const size_t shbytes = slots * 8 * sizeof(double);
   if (mode == 0)
     hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(grid), dim3(nthreads), shbytes, ST, part, ppg, groups, C, (double)count,
-                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, lpg, nbt);
   else
     hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(grid), dim3(nthreads), shbytes, ST, part, ppg, groups, C, (double)count,
-                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, nbt);
+                       gamma, beta, rmean, rvar, momentum, eps, out, dgamma, dbeta, accumulate, qpb, lpg, nbt);
   S2I_LAUNCH_CHECK("bn_finalize");
   return 0;
 }
