@@ -3,9 +3,10 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from speech_to_image_translation_without_text_amd import model, trainer as T
+from speech_to_image_translation_without_text_amd import model, ops, trainer as T
 from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_from_file
-dev = torch.device("cuda:0"); B = 24
+dev = torch.device("cuda:0"); B = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+ops.ACT_BF16 = len(sys.argv) > 2 and sys.argv[2] == "bf16"
 cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
 torch.manual_seed(0)
 netG = model.G_NET(); netG.apply(T.weights_init)
