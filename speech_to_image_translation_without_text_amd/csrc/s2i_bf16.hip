@@ -144,6 +144,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
     arow[i] = (tb * PH + (KIND == KB_K4S2 ? 2 * ty : ty)) * PW + tx;
   }
+  // weight fragment rows of this lane inside one tap's [BN][CK] image (BN is a multiple of the swizzle period, so the
+  // tap only adds tl * BN * ROWB)
+  int boffs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int brow = wn * TN * 32 + j * 32 + l31;
+    boffs[j] = brow * ROWB + ((lh ^ ((brow >> LGR) & (SEGS - 1))) << 4);
+  }
   // weight stage: segment e -> (tap, n, seg); global element offset inside the stage and swizzled LDS offset
   // (computed on the fly: BN and SEGS are powers of two)
   const int wstage = TG * p.Npad * CK;               // elements per (chunk, tap group)
@@ -219,10 +227,13 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     if (st + 1 < s_end) fetch(st + 1, ((st + 1) % NG) == 0);
     const int tg = st % NG;
     const unsigned char* Bcur = DMA ? Bs + ((st - s_begin) & 1) * B_BYTES : Bs;
-    // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (two named register sets,
-    // order pinned): the LDS latency hides behind this wave's own MFMAs, and no more than two sets are ever live
-    auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
-      const int tl = stp / KS, ks = stp % KS;
+    // LDS byte offsets of this lane's fragments, once per stage: the matrix loop below then spends no vector
+    // instructions on addresses (row, swizzle and tap arithmetic per read had the address math competing with the MFMAs
+    // for the SIMD's issue slots).  k-step ks of a tap is the ks = 0 offset XOR (ks << 5): the segment index is
+    // (2 ks) ^ lh ^ swizzle(row).
+    int aaddr[TM][TG];
+#pragma unroll
+    for (int tl = 0; tl < TG; ++tl) {
       const int t = tg * TG + tl;
       int toff;  // patch rows between tap (0,0) and tap t
       if (KIND == KB_K3S1) { toff = (t / 3) * PW + (t % 3); }
@@ -231,13 +242,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int prow = arow[i] + toff;
-        a[i] = *reinterpret_cast<const bf16x8*>(As + prow * ROWB + (((ks * 2 + lh) ^ ((prow >> LGR) & (SEGS - 1))) << 4));
+        aaddr[i][tl] = prow * ROWB + ((lh ^ ((prow >> LGR) & (SEGS - 1))) << 4);
       }
+    }
+    // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s are issued (two named register sets,
+    // order pinned): the LDS latency hides behind this wave's own MFMAs, and no more than two sets are ever live
+    auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+      const int tl = stp / KS, ks = stp % KS;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int brow = tl * BN + wn * TN * 32 + j * 32 + l31;
-        b[j] = *reinterpret_cast<const bf16x8*>(Bcur + brow * ROWB + (((ks * 2 + lh) ^ ((brow >> LGR) & (SEGS - 1))) << 4));
-      }
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(As + (aaddr[i][tl] ^ (ks << 5)));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bcur + tl * BN * ROWB + (boffs[j] ^ (ks << 5)));
     };
     auto mma = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
 #pragma unroll

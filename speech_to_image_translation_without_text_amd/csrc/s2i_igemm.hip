@@ -18,6 +18,7 @@
 // (ds_read_b32, conflict-free).  Global->LDS staging goes through registers with the next chunk's
 // loads in flight during the MFMA loop.
 #include "s2i_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -839,6 +840,156 @@ __global__ __launch_bounds__(256) void small_n_conv_kernel(IgemmP p) {
           else p.y[row * p.ldy + n] = o[n];
         }
       }
+    }
+  }
+}
+
+// ---- thin layers: 3 (4) channels on one side --------------------------------------------------------------------------
+// GET_IMAGE_G's conv3x3 -> RGB and the input gradient of the discriminators' first conv (few OUTPUT channels), the first
+// discriminator conv itself and GET_IMAGE_G's input gradient (4 INPUT channels): ONE LANE PER OUTPUT PIXEL on the vector
+// units, the weights as wave-uniform operands (scalar loads of a [phase][tap][k][n] fp32 table prepared by
+// thin_table_kernel), so an FMA needs no LDS read and no cross-lane reduction.  HBM-bound by design; the 32-wide matrix
+// tiles are 7/8 padding here and the lanes-per-pixel kernel above spends most of its time in LDS weight reads and shuffles.
+__global__ void thin_table_kernel(const float* __restrict__ P, float* __restrict__ table, int kind, int flip, int T, int wt,
+                                  int wR, int ldw, int Kk, int Nn, int nphases) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = nphases * T * Kk * Nn;
+  if (e >= total) return;
+  const int n = e % Nn, k = (e / Nn) % Kk, t = (e / (Nn * Kk)) % T, ph = e / (Nn * Kk * T);
+  const int tw = tap_weight(kind, flip, T, t, ph >> 1, ph & 1);
+  float v = 0.f;
+  if (wt) { if (n < wR && k < ldw) v = P[((size_t)tw * wR + n) * ldw + k]; }
+  else { if (k < wR && n < ldw) v = P[((size_t)tw * wR + k) * ldw + n]; }
+  table[e] = v;
+}
+
+__device__ __forceinline__ void load8(const IgemmP& p, long long xe, float (&v)[8]) {
+  if (p.x16) {
+    const u32x4 h = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = __builtin_bit_cast(float, h[j] << 16);
+      v[2 * j + 1] = __builtin_bit_cast(float, h[j] & 0xffff0000u);
+    }
+  } else {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p.x + xe), b = *reinterpret_cast<const f32x4*>(p.x + xe + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+  }
+}
+
+// <= 4 output channels: y[pix][0..3] = act(sum_{t,c} x[pix + t][c] * table[phase][t][c][0..3] + bias)
+__global__ __launch_bounds__(256) void thin_out_kernel(IgemmP p, const float* __restrict__ table) {
+  const int phase = blockIdx.z, py = phase >> 1, px = phase & 1;
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+  const float* __restrict__ wph = table + (size_t)phase * p.T * p.Ca * 4;
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+    const int b = m >> p.lgHoWo;
+    const int r = m & ((1 << p.lgHoWo) - 1);
+    const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+    const int by = oy * s - pad, bx = ox * s - pad;
+    const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px);
+    const long long xo = (((long long)b * p.H + by) * p.W + bx) * p.Cx;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+      if (!((mask >> t) & 1u)) continue;
+      int dy, dx;
+      tap_delta(p.kind, kw, t, py, px, dy, dx);
+      const long long xe = xo + ((long long)dy * p.W + dx) * p.Cx;
+      for (int c0 = 0; c0 < p.Ca; c0 += 8) {
+        float v[8];
+        load8(p, xe + c0, v);
+        const float* __restrict__ w = wph + ((size_t)t * p.Ca + c0) * 4;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          a0 = fmaf(v[j], w[j * 4 + 0], a0);
+          a1 = fmaf(v[j], w[j * 4 + 1], a1);
+          a2 = fmaf(v[j], w[j * 4 + 2], a2);
+          a3 = fmaf(v[j], w[j * 4 + 3], a3);
+        }
+      }
+    }
+    long long row = m;
+    if (p.kind == S2I_TCONV_K4S2) row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+    f32x4 o = {a0, a1, a2, a3};
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float v = o[n];
+      if (p.bias && n < p.N) v += p.bias[n];
+      if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+      else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+      else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+      o[n] = v;
+    }
+    if (p.N == 4 && !p.y16 && (p.ldy & 3) == 0) {
+      *reinterpret_cast<f32x4*>(p.y + row * p.ldy) = o;
+    } else {
+      for (int n = 0; n < p.N && n < 4; ++n) {
+        if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(o[n]);
+        else p.y[row * p.ldy + n] = o[n];
+      }
+    }
+  }
+}
+
+// 4 input channels, NOUT outputs: y[pix][n] = act(sum_{t,ci} x[pix + t][ci] * table[t][ci][n])
+template <int NOUT>
+__global__ __launch_bounds__(256) void thin_in_kernel(IgemmP p, const float* __restrict__ table) {
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < p.M; m += gridDim.x * 256) {
+    const int b = m >> p.lgHoWo;
+    const int r = m & ((1 << p.lgHoWo) - 1);
+    const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+    const int by = oy * s - pad, bx = ox * s - pad;
+    const unsigned mask = tap_mask(p.kind, kw, by, bx, p.H, p.W, 0, 0);
+    const long long xo = (((long long)b * p.H + by) * p.W + bx) * 4;
+    float acc[NOUT];
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[n] = 0.f;
+    for (int t = 0; t < p.T; ++t) {
+      if (!((mask >> t) & 1u)) continue;
+      int dy, dx;
+      tap_delta(p.kind, kw, t, 0, 0, dy, dx);
+      const long long xe = xo + ((long long)dy * p.W + dx) * 4;
+      f32x4 xv;
+      if (p.x16) {
+        const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+        xv = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+      } else {
+        xv = *reinterpret_cast<const f32x4*>(p.x + xe);
+      }
+      const float* __restrict__ w = table + (size_t)t * 4 * NOUT;   // wave-uniform
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) acc[n] = fmaf(xv[ci], w[ci * NOUT + n], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) {
+      float v = acc[n];
+      if (p.bias) v += p.bias[n];
+      if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+      else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+      else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+      acc[n] = v;
+    }
+    if (p.y16) {
+      unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + (long long)m * p.ldy;
+#pragma unroll
+      for (int g = 0; g < NOUT / 8; ++g) {
+        u32x4 o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) o[h] = (unsigned)f2bf(acc[g * 8 + 2 * h]) | ((unsigned)f2bf(acc[g * 8 + 2 * h + 1]) << 16);
+        *reinterpret_cast<u32x4*>(yp + g * 8) = o;
+      }
+    } else {
+      float* yp = p.y + (long long)m * p.ldy;
+#pragma unroll
+      for (int g = 0; g < NOUT / 4; ++g)
+        *reinterpret_cast<f32x4*>(yp + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
     }
   }
 }
@@ -1825,9 +1976,27 @@ void launch_fwd(const IgemmP& p, dim3 grid, bool wt, bool ca32, hipStream_t st) 
 
 }  // namespace
 
+// thin layers (one lane per output pixel, weights as a scalar table in the workspace): 1 = few outputs, 2 = 4 inputs
+static int thin_kind(const s2i_conv_desc* d, const FwdPlan& pl) {
+  if (d->Cc != 0 || d->stats || pl.M < 4096 || pl.splitk != 1) return 0;
+  // measured (bf16 mode, batch 48): few outputs from 16 / 32 channels 113 / 66 us against 273 / 135 us for the
+  // lanes-per-pixel kernel; from 64 channels the lane-per-pixel reads (128-byte pixels, one 16-byte piece per instruction)
+  // thrash L1: 703 against 280 us, so that case stays with small_n_conv_kernel.  4 inputs to 16 / 32 outputs 78 / 43 us
+  // against 225 / 64 us on the matrix kernel; to 64 outputs (first discriminator conv, 4096 FMAs per pixel) the vector
+  // units tie with the fp32 matrix kernel (310 vs 315 us) and lose at batch 48 (152 vs 113): not taken.
+  if (d->N <= 4 && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) && (pl.Ca % 8) == 0 && pl.Ca <= 32) return 1;
+  if (pl.Ca == 4 && d->kind == S2I_CONV_K3S1 && (d->N == 16 || d->N == 32) && (d->ldy % 8) == 0) return 2;
+  return 0;
+}
+static size_t thin_table_floats(const s2i_conv_desc* d, const FwdPlan& pl, int tk) {
+  return tk == 1 ? (size_t)pl.nphases * pl.T * pl.Ca * 4 : (size_t)pl.T * 4 * d->N;
+}
+
 extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 0;
+  const int tk = thin_kind(d, pl);
+  if (tk) return thin_table_floats(d, pl, tk) * sizeof(float);
   return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
 }
 
@@ -1940,6 +2109,30 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   p.x16 = x16; p.y16 = y16;
   S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
+  static const bool thin_on = !(getenv("S2I_THIN") && atoi(getenv("S2I_THIN")) == 0);
+  const int tk = (!wsp && !cls_bias && thin_on) ? thin_kind(d, pl) : 0;
+  if (tk && ws && ws_bytes >= thin_table_floats(d, pl, tk) * sizeof(float)) {
+    p.wt = d->wmode != 0;
+    float* table = (float*)ws;
+    const int Kk = tk == 1 ? pl.Ca : 4, Nn = tk == 1 ? 4 : d->N;
+    const int total = (tk == 1 ? pl.nphases : 1) * pl.T * Kk * Nn;
+    hipLaunchKernelGGL(thin_table_kernel, dim3(s2i_cdiv(total, 256)), dim3(256), 0, st, w, table, d->kind, d->flip, pl.T,
+                       d->wmode != 0 ? 1 : 0, d->wR, d->ldw, Kk, Nn, tk == 1 ? pl.nphases : 1);
+    S2I_LAUNCH_CHECK("thin_table");
+    int blocks = s2i_cdiv(pl.M, 256);
+    if (tk == 1) {
+      if (blocks > 4096 / pl.nphases) blocks = 4096 / pl.nphases;
+      // the table has 4 columns per (tap, channel); columns beyond N read the zero padding of the packed weights
+      hipLaunchKernelGGL(thin_out_kernel, dim3(blocks, 1, pl.nphases), dim3(256), 0, st, p, (const float*)table);
+    } else {
+      if (blocks > 4096) blocks = 4096;
+      if (d->N == 16) hipLaunchKernelGGL((thin_in_kernel<16>), dim3(blocks), dim3(256), 0, st, p, (const float*)table);
+      else if (d->N == 32) hipLaunchKernelGGL((thin_in_kernel<32>), dim3(blocks), dim3(256), 0, st, p, (const float*)table);
+      else hipLaunchKernelGGL((thin_in_kernel<64>), dim3(blocks), dim3(256), 0, st, p, (const float*)table);
+    }
+    S2I_LAUNCH_CHECK("thin_conv");
+    return 0;
+  }
   if (!wsp && d->N <= 4 && d->Cc == 0 && !d->stats && !cls_bias && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
       (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) && pl.M >= 4096) {
     // HBM-bound RGB-sized layers: VALU kernel instead of a 32-wide MFMA tile that is 7/8 padding
