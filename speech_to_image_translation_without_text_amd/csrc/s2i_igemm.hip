@@ -994,6 +994,162 @@ __global__ __launch_bounds__(256) void thin_in_kernel(IgemmP p, const float* __r
   }
 }
 
+// ---- bf16 mode: the 3-channel image layers on the bf16 matrix cores with PIXELS AS COLUMNS ---------------------------------
+// D = W (32 output-channel rows x K) . X^T (K x 32 pixels): the weights are the A operand and stay in registers for the whole
+// kernel (fragments prepared by rgb_afrag_kernel), the B fragment of a lane -- 8 consecutive K values of ITS pixel -- is 16
+// (bf16) or 32 (fp32 NHWC4: two adjacent taps) contiguous bytes of global memory, so no LDS, no barriers and no cross-lane
+// reduction; the result of a pixel sits in the registers of its own lane(s) and leaves as 8 / 16-byte stores.
+//   rgb_out: few output channels (GET_IMAGE_G's conv3x3 -> RGB, input gradient of the first discriminator conv)
+//   rgb_in : 4 input channels (first discriminator conv, input gradient of GET_IMAGE_G)
+__global__ void rgb_afrag_kernel(const float* __restrict__ P, unsigned short* __restrict__ out, int mode, int kind, int flip, int T,
+                                 int wt, int wR, int ldw, int CIN, int KW, int MT, int KSTEPS, int nphases, int Nreal) {
+  // out[phase][mt][ks][lane][8]; mode 0 (rgb_out): k = t * CIN + c;  mode 1 (rgb_in): k-step = kernel row, j = dxl * 4 + c
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = nphases * MT * KSTEPS * 64 * 8;
+  if (e >= total) return;
+  const int j = e & 7, lane = (e >> 3) & 63, ks = (e >> 9) % KSTEPS, mt = ((e >> 9) / KSTEPS) % MT, ph = (e >> 9) / (KSTEPS * MT);
+  const int n = mt * 32 + (lane & 31), kk = 8 * (lane >> 5) + j;
+  int t, c;
+  bool live = n < Nreal;
+  if (mode == 0) {
+    const int k = ks * 16 + kk;
+    t = k / CIN;
+    c = k - t * CIN;
+  } else {
+    const int dxl = kk >> 2;
+    c = kk & 3;
+    t = ks * KW + dxl;
+    live = live && dxl < KW;
+  }
+  float v = 0.f;
+  if (live) {
+    const int tw = tap_weight(kind, flip, T, t, ph >> 1, ph & 1);
+    if (wt) { if (n < wR && c < ldw) v = P[((size_t)tw * wR + n) * ldw + c]; }
+    else { if (c < wR && n < ldw) v = P[((size_t)tw * wR + c) * ldw + n]; }
+  }
+  out[e] = f2bf(v);
+}
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void rgb_out_kernel(IgemmP p, const unsigned short* __restrict__ afrag) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int phase = blockIdx.z, py = phase >> 1, px = phase & 1;
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+  bf16x8_t A[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks)
+    A[ks] = *reinterpret_cast<const bf16x8_t*>(afrag + ((size_t)(phase * KSTEPS + ks) * 64 + lane) * 8);
+  const int kpt = p.Ca / 16;                      // k-steps per tap
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x);
+  const int ngroups = (p.M + 31) / 32;
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int m = grp * 32 + l31;
+    const bool live = m < p.M;
+    const int b = m >> p.lgHoWo;
+    const int r = m & ((1 << p.lgHoWo) - 1);
+    const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+    const int by = oy * s - pad, bx = ox * s - pad;
+    const unsigned mask = live ? tap_mask(p.kind, kw, by, bx, p.H, p.W, py, px) : 0u;
+    const long long xo = (((long long)b * p.H + by) * p.W + bx) * p.Cx + 8 * lh;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int t = ks / kpt, c0 = (ks - t * kpt) * 16;
+      int dy, dx;
+      tap_delta(p.kind, kw, t, py, px, dy, dx);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if ((mask >> t) & 1u) v = *reinterpret_cast<const u32x4*>(xb + xo + ((long long)dy * p.W + dx) * p.Cx + c0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], __builtin_bit_cast(bf16x8_t, v), acc, 0, 0, 0);
+    }
+    if (lh == 0 && live) {                       // rows 0..3 of column l31 = registers 0..3 of this lane
+      long long row = m;
+      if (p.kind == S2I_TCONV_K4S2) row = ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        float v = o[n];
+        if (p.bias && n < p.N) v += p.bias[n];
+        if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+        else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+        o[n] = v;
+      }
+      if (p.N == 4 && (p.ldy & 3) == 0) *reinterpret_cast<f32x4*>(p.y + row * p.ldy) = o;
+      else
+        for (int n = 0; n < p.N && n < 4; ++n) p.y[row * p.ldy + n] = o[n];
+    }
+  }
+}
+
+// MT = output-channel tiles of 32; KH = kernel rows = k-steps (a k-step holds the 4 horizontal taps x 4 channels of one row;
+// the 3x3 has a zero fourth tap)
+template <int MT, int KH>
+__global__ __launch_bounds__(256) void rgb_in_kernel(IgemmP p, const unsigned short* __restrict__ afrag) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int s, pad, kw;
+  geom(p, p.kind, s, pad, kw);
+  bf16x8_t A[MT][KH];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+      A[mt][ks] = *reinterpret_cast<const bf16x8_t*>(afrag + ((size_t)(mt * KH + ks) * 64 + lane) * 8);
+  unsigned short* yb = reinterpret_cast<unsigned short*>(p.y);
+  const int ngroups = (p.M + 31) / 32;
+  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
+    const int m = grp * 32 + l31;
+    const bool live = m < p.M;
+    const int b = m >> p.lgHoWo;
+    const int r = m & ((1 << p.lgHoWo) - 1);
+    const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
+    const int by = oy * s - pad, bx = ox * s - pad + 2 * lh;   // this lane's two taps: columns bx, bx + 1
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mt][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks) {
+      const int iy = by + ks;
+      const bool rowok = live && iy >= 0 && iy < p.H;
+      const float* xp = p.x + (((long long)b * p.H + iy) * p.W + bx) * 4;
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+      if (rowok && bx >= 0 && bx < p.W) v0 = *reinterpret_cast<const f32x4*>(xp);
+      if (rowok && bx + 1 >= 0 && bx + 1 < p.W) v1 = *reinterpret_cast<const f32x4*>(xp + 4);
+      bf16x8_t bv = {(__bf16)v0[0], (__bf16)v0[1], (__bf16)v0[2], (__bf16)v0[3],
+                     (__bf16)v1[0], (__bf16)v1[1], (__bf16)v1[2], (__bf16)v1[3]};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][ks], bv, acc[mt], 0, 0, 0);
+    }
+    if (!live) continue;
+    // column l31 (this pixel): registers 4g..4g+3 of tile mt = channels mt*32 + 8g + 4lh + (0..3)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = mt * 32 + 8 * g + 4 * lh;
+        if (n >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v = acc[mt][4 * g + q];
+          if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+          else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+          o[q] = v;
+        }
+        *reinterpret_cast<u32x2_t*>(yb + (long long)m * p.ldy + n) =
+            u32x2_t{(unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16), (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16)};
+      }
+  }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, int S, long long rows, int N,
                                      const float* __restrict__ bias, int act, float* __restrict__ y,
                                      int ldy, int y16) {
@@ -1992,11 +2148,33 @@ static size_t thin_table_floats(const s2i_conv_desc* d, const FwdPlan& pl, int t
   return tk == 1 ? (size_t)pl.nphases * pl.T * pl.Ca * 4 : (size_t)pl.T * 4 * d->N;
 }
 
+// bf16-mode image layers on the matrix cores with pixels as columns: 1 = few outputs from bf16 input, 2 = fp32 NHWC4 input to
+// bf16 output (the dtype combination decides: these are the edges of the bf16 activation mode only)
+static int rgb_kind(const s2i_conv_desc* d, const FwdPlan& pl, int x16, int y16) {
+  if (d->Cc != 0 || d->stats || pl.M < 4096) return 0;
+  if (x16 && !y16 && d->N <= 4 && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_TCONV_K4S2) &&
+      (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64))
+    return 1;
+  if (!x16 && y16 && pl.Ca == 4 && (d->kind == S2I_CONV_K3S1 || d->kind == S2I_CONV_K4S2) &&
+      (d->N == 16 || d->N == 32 || d->N == 64) && (d->ldy % 4) == 0)
+    return 2;
+  return 0;
+}
+static size_t rgb_afrag_elems(const s2i_conv_desc* d, const FwdPlan& pl, int rk) {
+  if (rk == 1) return (size_t)pl.nphases * (pl.T * pl.Ca / 16) * 64 * 8;
+  return (size_t)((d->N + 31) / 32) * (d->kind == S2I_CONV_K4S2 ? 4 : 3) * 64 * 8;
+}
+
 extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 0;
   const int tk = thin_kind(d, pl);
-  if (tk) return thin_table_floats(d, pl, tk) * sizeof(float);
+  // the dtype-dependent rgb kernels need at most this much as well (bf16 fragments; sized for either)
+  size_t rgb = 0;
+  if (rgb_kind(d, pl, 1, 0)) rgb = rgb_afrag_elems(d, pl, 1) * 2;
+  if (rgb_kind(d, pl, 0, 1)) rgb = rgb_afrag_elems(d, pl, 2) * 2;
+  if (tk) { const size_t tb = thin_table_floats(d, pl, tk) * sizeof(float); return tb > rgb ? tb : rgb; }
+  if (rgb) return rgb;
   return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
 }
 
@@ -2109,6 +2287,37 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   p.x16 = x16; p.y16 = y16;
   S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
+  static const bool rgb_on = !(getenv("S2I_RGB") && atoi(getenv("S2I_RGB")) == 0);
+  const int rk = (!wsp && !cls_bias && rgb_on) ? rgb_kind(d, pl, x16, y16) : 0;
+  if (rk && ws && ws_bytes >= rgb_afrag_elems(d, pl, rk) * 2 && !(rk == 2 && bias)) {
+    unsigned short* afrag = (unsigned short*)ws;
+    const int total = (int)rgb_afrag_elems(d, pl, rk);
+    const int KW = d->kind == S2I_CONV_K4S2 ? 4 : 3;
+    const int MT = rk == 1 ? 1 : (d->N + 31) / 32, KS = rk == 1 ? pl.T * pl.Ca / 16 : (d->kind == S2I_CONV_K4S2 ? 4 : 3);
+    hipLaunchKernelGGL(rgb_afrag_kernel, dim3(s2i_cdiv(total, 256)), dim3(256), 0, st, w, afrag, rk == 1 ? 0 : 1, d->kind, d->flip,
+                       pl.T, d->wmode != 0 ? 1 : 0, d->wR, d->ldw, pl.Ca, KW, MT, KS, rk == 1 ? pl.nphases : 1, d->N);
+    S2I_LAUNCH_CHECK("rgb_afrag");
+    int blocks = s2i_cdiv(pl.M, 128);
+    if (blocks > 2048) blocks = 2048;
+    if (rk == 1) {
+      dim3 g(blocks > 2048 / pl.nphases ? 2048 / pl.nphases : blocks, 1, pl.nphases);
+      if (KS == 9) hipLaunchKernelGGL((rgb_out_kernel<9>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 18) hipLaunchKernelGGL((rgb_out_kernel<18>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 36) hipLaunchKernelGGL((rgb_out_kernel<36>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 4) hipLaunchKernelGGL((rgb_out_kernel<4>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 8) hipLaunchKernelGGL((rgb_out_kernel<8>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 16) hipLaunchKernelGGL((rgb_out_kernel<16>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else S2I_FAIL("rgb_out: unexpected k-step count %d", KS);
+    } else {
+      dim3 g(blocks);
+      if (KS == 4 && MT == 2) hipLaunchKernelGGL((rgb_in_kernel<2, 4>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (KS == 4) hipLaunchKernelGGL((rgb_in_kernel<1, 4>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else if (MT == 2) hipLaunchKernelGGL((rgb_in_kernel<2, 3>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+      else hipLaunchKernelGGL((rgb_in_kernel<1, 3>), g, dim3(256), 0, st, p, (const unsigned short*)afrag);
+    }
+    S2I_LAUNCH_CHECK("rgb_conv");
+    return 0;
+  }
   static const bool thin_on = !(getenv("S2I_THIN") && atoi(getenv("S2I_THIN")) == 0);
   const int tk = (!wsp && !cls_bias && thin_on) ? thin_kind(d, pl) : 0;
   if (tk && ws && ws_bytes >= thin_table_floats(d, pl, tk) * sizeof(float)) {

@@ -200,6 +200,52 @@ def test_bf16_fused_block_tracks_fp32_reference(gpu, case, bf16_mode):
     assert int(nbt.item()) == 1
 
 
+IMAGE_LAYERS = [
+    # (kind, B, H, Cin true, Cin stored, Cout true, n_out, act): the 3-channel edges of the bf16 mode
+    ("k3s1", 2, 64, 16, 16, 3, 4, "tanh"),     # GET_IMAGE_G: bf16 features -> fp32 RGB (pixels-as-columns MFMA kernel)
+    ("k3s1", 2, 64, 32, 32, 3, 4, "tanh"),
+    ("k3s1", 3, 64, 64, 64, 3, 4, "tanh"),
+    ("k4s2", 2, 64, 3, 4, 64, 64, "lrelu"),    # first discriminator conv: fp32 NHWC4 image -> bf16 features
+    ("k4s2", 2, 128, 3, 4, 32, 32, "lrelu"),
+    ("k4s2", 3, 64, 3, 4, 16, 16, "lrelu"),
+]
+
+
+@pytest.mark.parametrize("case", IMAGE_LAYERS, ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16_image_layers_forward_and_gradients(gpu, case, bf16_mode):
+    """ConvAct at the image edges of the bf16 mode (model.py:287-298, 383-384): forward, input gradient and weight gradient
+    against torch fp32 on the same inputs; bf16 products with fp32 accumulation: 1.5e-2 relative L2."""
+    from test_kernels_gpu import ACT
+    from speech_to_image_translation_without_text_amd import ops
+    kind, B, H, Cin, Cs, Cout, n_out, act = case
+    g = torch.Generator().manual_seed(zlib.crc32(repr(case).encode()) % 100000)
+    kk = 3 if kind == "k3s1" else 4
+    x = r16(torch.randn(B, Cin, H, H, generator=g))
+    w = torch.randn(Cout, Cin, kk, kk, generator=g) / (kk * Cin ** 0.5)
+    Ho = H if kind == "k3s1" else H // 2
+    gout = r16(torch.randn(B, Cout, Ho, Ho, generator=g))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xr, wr, padding=1, stride=1 if kind == "k3s1" else 2)
+    y = torch.tanh(y) if act == "tanh" else F.leaky_relu(y, 0.2)
+    y.backward(gout)
+    xs = torch.zeros(B, Cs, H, H)
+    xs[:, :Cin] = x
+    xg = nhwc(xs).to(gpu)
+    xg = (xg.to(torch.bfloat16) if Cs >= 8 else xg).requires_grad_(True)
+    wg = w.to(gpu).requires_grad_(True)
+    out = ops.ConvAct.apply(xg, wg, None, kind, ACT[act], n_out)
+    assert out.dtype == (torch.bfloat16 if n_out >= 8 else torch.float32)
+    gs = torch.zeros(B, n_out, Ho, Ho)
+    gs[:, :Cout] = gout
+    out.backward(nhwc(gs).to(gpu).to(out.dtype))
+    torch.cuda.synchronize()
+    dev = dict(out=rel_l2(nchw(out.float())[:, :Cout], y), dx=rel_l2(nchw(xg.grad.float())[:, :Cin], xr.grad),
+               dw=rel_l2(wg.grad, wr.grad))
+    print("bf16 image layer %s: relative L2 deviation from fp32" % (case,), {k: "%.2e" % v for k, v in dev.items()})
+    for k, v in dev.items():
+        assert v <= (6e-2 if (act == "lrelu" and k != "out") else 1.5e-2), (k, v, dev)
+
+
 def _run_steps(gpu, case, n_steps, bf16):
     from speech_to_image_translation_without_text_amd import ops, trainer as T
     old = ops.ACT_BF16
