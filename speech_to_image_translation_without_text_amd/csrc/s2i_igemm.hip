@@ -1508,7 +1508,9 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
 // Weight gradient with BOTH operands stored as bf16 (bf16 activation mode): the structure of igemm_wgrad_split_kernel
 // with one plane, but the staged values are already bf16, so a 16-byte load (8 channels of one pixel) is copied to
 // LDS as it is, and a stage is 64 pixels deep (4 k-steps, 16 MFMAs per wave between two barriers instead of 8).
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+// A32: the gathered operand is the fp32 NHWC4 image of the first discriminator conv (4x4 stride 2): 8 consecutive K columns
+// are two horizontally adjacent taps x 4 channels = 32 contiguous bytes, converted to bf16 while they are staged.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool A32 = false>
 __global__ __launch_bounds__(256, 3) void igemm_wgrad_b16_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int PC = 64;                               // pixels per stage
@@ -1549,8 +1551,17 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_b16_kernel(WgradP p) {
       const int r = m & ((1 << p.lgHoWo) - 1);
       const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
       const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
-      const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      ra[q] = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, ok ? (((b * p.H + iy) * p.W + ix) * p.Ca + c) * 2 : S2I_OOB, 0, 0);
+      if constexpr (A32) {
+        const bool rowok = kvalid && m < p.M && iy >= 0 && iy < p.H;
+        const int o0 = ((b * p.H + iy) * p.W + ix) * 16;      // byte offset of pixel (iy, ix): 4 fp32 channels
+        const f32x4 v0 = bload4(ra_rs, (rowok && ix >= 0 && ix < p.W) ? o0 : S2I_OOB);
+        const f32x4 v1 = bload4(ra_rs, (rowok && ix + 1 >= 0 && ix + 1 < p.W) ? o0 + 16 : S2I_OOB);
+        ra[q] = u32x4{(unsigned)f2bf(v0[0]) | ((unsigned)f2bf(v0[1]) << 16), (unsigned)f2bf(v0[2]) | ((unsigned)f2bf(v0[3]) << 16),
+                      (unsigned)f2bf(v1[0]) | ((unsigned)f2bf(v1[1]) << 16), (unsigned)f2bf(v1[2]) | ((unsigned)f2bf(v1[3]) << 16)};
+      } else {
+        const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        ra[q] = __builtin_amdgcn_raw_buffer_load_b128(ra_rs, ok ? (((b * p.H + iy) * p.W + ix) * p.Ca + c) * 2 : S2I_OOB, 0, 0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
@@ -2173,8 +2184,10 @@ extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
   size_t rgb = 0;
   if (rgb_kind(d, pl, 1, 0)) rgb = rgb_afrag_elems(d, pl, 1) * 2;
   if (rgb_kind(d, pl, 0, 1)) rgb = rgb_afrag_elems(d, pl, 2) * 2;
-  if (tk) { const size_t tb = thin_table_floats(d, pl, tk) * sizeof(float); return tb > rgb ? tb : rgb; }
-  if (rgb) return rgb;
+  // the caller does not know which kernel the dtypes will select: the largest requirement of the candidates
+  size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
+  if (tk) { const size_t tb = thin_table_floats(d, pl, tk) * sizeof(float); need = tb > need ? tb : need; }
+  if (rgb || tk) return rgb > need ? rgb : need;
   return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
 }
 
@@ -2482,7 +2495,18 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
-  if (a16 && g16 && !pl.small_n && d->Cc == 0 && (pl.Cin % 8) == 0 && (d->N % 8) == 0 && (d->ldg % 8) == 0) {
+  static const bool a32_on = !(getenv("S2I_WGRAD_A32") && atoi(getenv("S2I_WGRAD_A32")) == 0);
+  if (a32_on && !a16 && g16 && d->kind == S2I_CONV_K4S2 && d->Ca == 4 && d->Cc == 0 && pl.K == 64 && d->N <= 64 && (d->N % 8) == 0 &&
+      (d->ldg % 8) == 0) {
+    // first discriminator conv: fp32 NHWC4 image x bf16 output gradient on the bf16 matrix cores
+    WgradP q = p;
+    q.nchunks = s2i_cdiv(pl.M, 64);
+    q.cps = s2i_cdiv(q.nchunks, pl.splitk);
+    dim3 g32(1, 1, s2i_cdiv(q.nchunks, q.cps));
+    pl.splitk = (int)g32.z;
+    pl.gridK = 1; pl.gridN = 1;
+    hipLaunchKernelGGL((igemm_wgrad_b16_kernel<64, 64, 2, 2, true>), g32, dim3(256), 0, st, q);
+  } else if (a16 && g16 && !pl.small_n && d->Cc == 0 && (pl.Cin % 8) == 0 && (d->N % 8) == 0 && (d->ldg % 8) == 0) {
     // both operands bf16: 64-pixel stages on the bf16 matrix cores
     WgradP q = p;
     q.nchunks = s2i_cdiv(pl.M, 64);
