@@ -176,6 +176,9 @@ int    s2i_conv_bf16_eligible(const s2i_conv_desc* d);
 size_t s2i_conv_bf16_workspace_bytes(const s2i_conv_desc* d);
 int    s2i_conv_bf16_stat_parts(const s2i_conv_desc* d);
 size_t s2i_conv_bf16_weight_elems(const s2i_conv_desc* d);
+/* Identifies the weight arrangement (CK | Npad << 8) the plan of this descriptor consumes: the same layer at another batch
+ * size or map size may be planned onto another kernel, so a cache of packed bf16 weights is keyed by it.  -1 on error. */
+int    s2i_conv_bf16_weight_layout(const s2i_conv_desc* d);
 int s2i_pack_conv_weight_bf16(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
                               void* stream);
 int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned short* x, const unsigned short* w,

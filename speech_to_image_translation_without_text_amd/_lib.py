@@ -56,6 +56,7 @@ _SIGNATURES = {
     "s2i_conv_bf16_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_bf16_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_bf16_weight_elems": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "s2i_conv_bf16_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_pack_conv_weight_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, c_int, P, P]),
     "s2i_conv_forward_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     "s2i_conv_forward_dt": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),

@@ -21,6 +21,8 @@
 // from the map size, e.g. 4 x 32 pixels of one image on wide maps, 8 whole 4x4 maps at the discriminators' tails.
 #include "s2i_common.h"
 #include <stdlib.h>
+#include <stdio.h>
+#include <vector>
 
 namespace {
 
@@ -112,6 +114,21 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
+  // DBG & 32 (diagnostic build of tools/conv16_timeline.py only): wave 0 stamps s_memtime at the phase boundaries into a
+  // buffer of its own (p.slab, 64 stamps per block); no stamp executes in the production instantiation
+  auto stamp = [&](int i) {
+    if constexpr ((DBG & 32) != 0) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (tid == 0) {
+        const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        reinterpret_cast<unsigned long long*>(p.slab)[blk * 64 + i] = t;
+      }
+    }
+  };
+  stamp(0);
   // ---- patch staging plan of this thread: global byte offset (chunk 0) and swizzled LDS offset per load ----
   int pgo[NPL], plo[NPL];
   const int nseg = p.npix * SEGS;
@@ -219,11 +236,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (s_begin < s_end) fetch(s_begin, true);
+  stamp(1);
   for (int st = s_begin; st < s_end; ++st) {
     const bool new_a = (st % NG) == 0;
+    const int sb = 2 + 6 * min(st - s_begin, 7);
+    stamp(sb);
     if (!((DBG & 4) && st != s_begin)) stage(new_a);
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this stage's weights have landed in LDS
+    stamp(sb + 1);
     __syncthreads();
+    stamp(sb + 2);
     if (st + 1 < s_end) fetch(st + 1, ((st + 1) % NG) == 0);
     const int tg = st % NG;
     const unsigned char* Bcur = DMA ? Bs + ((st - s_begin) & 1) * B_BYTES : Bs;
@@ -264,6 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
           else asm volatile("" :: "v"(a[i]), "v"(b[j]));  // keeps the fragment reads alive
     };
     constexpr int NS = TG * KS;
+    stamp(sb + 3);
     if constexpr (PIN) {
       bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
       ldfr(0, a0, b0);
@@ -288,7 +311,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     }
     // DMA: the other weight buffer is refilled only after the next leading barrier, so the trailing barrier is needed
     // only where the (single) patch buffer is about to be overwritten, and before the epilogue reuses LDS
+    stamp(sb + 4);
     if (!DMA || st + 1 >= s_end || ((st + 1) % NG) == 0) __syncthreads();
+    stamp(sb + 5);
   }
 
   // ---- epilogue ----
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
         *reinterpret_cast<unsigned*>(smem + rr * ERS + col * 2) = v;
       }
   __syncthreads();
+  stamp(50);
   {
     constexpr int SPR = BN / 8;                       // 16-byte segments per row
 #pragma unroll
@@ -367,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
         *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
     }
   }
+  stamp(51);
   if (p.stats) {
     // column sums of the fp32 accumulators over this block's valid rows (rows beyond the batch gathered zeros)
     __syncthreads();
@@ -406,6 +433,419 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       }
     }
   }
+  stamp(52);
+  if constexpr ((DBG & 32) != 0) {
+    if (tid == 0) {
+      const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+      unsigned long long* o = reinterpret_cast<unsigned long long*>(p.slab) + blk * 64;
+      o[60] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+      o[61] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+      o[62] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+}
+
+// ---- second-generation kernel: 256 output pixels x 128 channels per block, 8 waves, everything prefetched two stages ahead --
+// What the in-kernel timeline of the 128-pixel kernel showed (tools/conv16_timeline.py): the matrix
+// loop was a quarter of a block's lifetime; the rest was the bulk issue of the next stage's loads (the CU's 64 B/clk
+// vector-memory path stalls the issuing wave, which then cannot feed the matrix pipe), waiting for loads issued only one
+// matrix phase earlier, two barriers per stage, and a prologue / epilogue per 33 MFLOP of work.  This kernel
+//   * doubles the pixel tile (the 256 KB weight stream of a block is amortised over twice the pixels: 40 % fewer bytes
+//     through the vector-memory path per FLOP),
+//   * issues every global load BETWEEN matrix instructions, a few per k-step, two stages (weights: two register sets
+//     that alternate) or a whole channel chunk (patch) before the data is needed, and moves it to LDS between matrix
+//     instructions of a later stage as well -- no bulk issue, no wait right after an issue,
+//   * keeps two weight stages (and, where the patch is small enough -- 3x3 and transposed phases -- two patch chunks) in
+//     LDS, so a stage ends with ONE barrier.
+// The schedule is compile-time: the stages of a channel chunk are unrolled (tap group tg, weight register set parity P),
+// so every vmcnt the compiler derives is exact.  Geometry, LDS images, swizzle, fragment maps and the epilogue are
+// those of conv_bf16_kernel.
+template <int V> struct IC { static constexpr int value = V; };
+
+template <int KIND, int CK, int TG, bool PDB, int DBG = 0>
+__global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
+  constexpr int BN = 128, BM = 256, NT = 512;
+  constexpr int T = KIND == KB_K3S1 ? 9 : (KIND == KB_K4S2 ? 16 : 4);
+  constexpr int NG = T / TG;
+  static_assert(NG * TG == T && NG >= 2, "tap groups must tile the taps, at least two stages per channel chunk");
+  constexpr int WAVES_N = 2, WAVES_M = 4, TM = 2, TN = 2;
+  constexpr int SEGS = CK / 8, ROWB = CK * 2;
+  constexpr int LGR = SEGS == 2 ? 3 : (SEGS == 4 ? 2 : 1);
+  constexpr int KS = CK / 16, NS = TG * KS, HS = NS / 2;      // k-steps per stage; the first HS issue loads, the rest store
+  static_assert((NS % 2) == 0, "even number of k-steps per stage");
+  constexpr int BSEG = TG * BN * SEGS, NBL = BSEG / NT, B_BYTES = TG * BN * ROWB;
+  static_assert(BSEG % NT == 0, "a weight stage is a whole number of 16-byte segments per thread");
+  constexpr int MAXPIX = KIND == KB_K4S2 ? 1280 : (KIND == KB_K3S1 ? 416 : 336);   // plan_bf16 checks the patch against this
+  constexpr int NPL = (MAXPIX * SEGS + NT - 1) / NT;
+  constexpr int ALS = NG - 1;                                 // stages of a chunk that issue the next chunk's patch loads
+  constexpr int AG = ALS * HS;                                // ... over this many k-step slots
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch (x2) | weight stage x2 | 1 KB sink]
+  const int A_BYTES = (p.npix * ROWB + 255) & ~255;
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + (PDB ? 2 : 1) * A_BYTES;
+  const int sink = (PDB ? 2 : 1) * A_BYTES + 2 * B_BYTES;     // lanes without a patch segment store here (no exec masks)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int phase = 0, split = blockIdx.z;
+  if (KIND == KB_TCONV) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  const int py = phase >> 1, px = phase & 1;
+  const int n0 = blockIdx.y * BN;
+  const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
+  const int tix = blockIdx.x & (p.tilesX - 1);
+  const int tiy = (blockIdx.x / p.tilesX) & (p.tilesY - 1);
+  const int tib = blockIdx.x / (p.tilesX * p.tilesY);
+  const int b0 = tib << p.lgTB, oy0 = tiy << p.lgTH, ox0 = tix << p.lgTW;
+  const int PW = p.PW, PH = p.PH;
+  int iy0, ix0;
+  if (KIND == KB_K3S1) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
+  else if (KIND == KB_K4S2) { iy0 = 2 * oy0 - 1; ix0 = 2 * ox0 - 1; }
+  else { iy0 = oy0 - (py ? 0 : 1); ix0 = ox0 - (px ? 0 : 1); }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+  // DBG & 32 (diagnostic build of tools/conv16_timeline.py): wave 0 stamps s_memtime into a buffer of its own
+  auto stamp = [&](int i) {
+    if constexpr ((DBG & 32) != 0) {
+      unsigned long long t;
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (tid == 0) {
+        const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+        reinterpret_cast<unsigned long long*>(p.slab)[blk * 64 + i] = t;
+      }
+    }
+  };
+  stamp(0);
+
+  // patch plan of this thread (as conv_bf16_kernel): global byte offset of segment q (chunk 0) and its swizzled LDS offset;
+  // segments beyond the patch load nothing and store to the sink.  The LDS offsets are kept in registers only where the
+  // matrix loop needs them (two patch buffers); the single-buffer form recomputes them at the chunk boundary.
+  const int nseg = p.npix * SEGS;
+  const float inv_pw = 1.0f / (float)PW, inv_ph = 1.0f / (float)PH;
+  auto patch_slot = [&](int q, int& go, int& lo) {
+    const int e = tid + q * NT;
+    go = S2I_OOB;
+    lo = -1;
+    if (e < nseg) {
+      const int pix = e / SEGS, seg = e & (SEGS - 1);
+      const int rest = (int)(((float)pix + 0.5f) * inv_pw);
+      const int xl = pix - rest * PW;
+      const int tb = (int)(((float)rest + 0.5f) * inv_ph);
+      const int yl = rest - tb * PH;
+      const int b = b0 + tb, iy = iy0 + yl, ix = ix0 + xl;
+      if (b < p.B && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) go = (((b * p.H + iy) * p.W + ix) * p.C + seg * 8) * 2;
+      const int xs = KIND == KB_K4S2 ? (xl & 1) * (PW >> 1) + (xl >> 1) : xl;
+      const int prow = (tb * PH + yl) * PW + xs;
+      lo = prow * ROWB + ((seg ^ ((prow >> LGR) & (SEGS - 1))) << 4);
+    }
+  };
+  int pgo[NPL], plo[PDB ? NPL : 1];
+#pragma unroll
+  for (int q = 0; q < NPL; ++q) {
+    int go, lo;
+    patch_slot(q, go, lo);
+    pgo[q] = go;
+    if (PDB) plo[q] = lo;
+  }
+  auto plo_of = [&](int q) -> int {
+    if (PDB) return plo[q];
+    int go, lo;
+    patch_slot(q, go, lo);
+    return lo;
+  };
+  auto adst = [&](unsigned char* base, int lo) -> u32x4* {
+    return reinterpret_cast<u32x4*>(lo >= 0 ? base + lo : smem + sink + lane * 16);
+  };
+  int arow[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * TM * 32 + i * 32 + l31;
+    const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
+    arow[i] = (tb * PH + (KIND == KB_K4S2 ? 2 * ty : ty)) * PW + tx;
+  }
+  int boffs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int brow = wn * TN * 32 + j * 32 + l31;
+    boffs[j] = brow * ROWB + ((lh ^ ((brow >> LGR) & (SEGS - 1))) << 4);
+  }
+  // weight stage segments of this thread: segment q is row (tid / SEGS) + q * (NT / SEGS) of the stage's [TG * BN][CK]
+  // image, so both its global offset and its swizzled LDS offset are the q = 0 values plus a constant
+  static_assert(BN % (NT / SEGS) == 0 && ((NT / SEGS) >> LGR) % SEGS == 0, "weight rows per load step keep the swizzle");
+  const int bseg = tid & (SEGS - 1), brow0 = tid / SEGS;
+  const int bgo0 = (brow0 * CK + bseg * 8) * 2;
+  const int blo0 = brow0 * ROWB + ((bseg ^ ((brow0 >> LGR) & (SEGS - 1))) << 4);
+  auto bgo_s = [&](int q) -> int {   // uniform part of the global byte offset of segment q
+    const int row = q * (NT / SEGS), n = row & (BN - 1), t = row / BN;
+    return ((t * p.Npad + n) * CK) * 2;
+  };
+  constexpr int BLO_STEP = (NT / SEGS) * ROWB;
+  const int wstage = TG * p.Npad * CK;                        // elements per (chunk, tap group)
+  const int c_begin = split * p.cps;
+  const int c_end = min(p.nchunk, c_begin + p.cps);
+  // byte base of stage (cc, tg) in the weight buffer, or out of range (the loads then return zeros and move nothing)
+  auto wbyte = [&](int cc, int tg) -> int { return (((phase * p.nchunk + cc) * NG + tg) * wstage + n0 * CK) * 2; };
+  // loads: the per-lane offset goes in the vector offset (out of range where nothing is to be loaded), the uniform part in
+  // the scalar offset
+  auto bload16s = [&](__amdgpu_buffer_rsrc_t r, int voff, int soff) -> u32x4 {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  };
+
+  u32x4 ra[NPL], rb[2][NBL];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stamp(1);
+  // ---- prologue: patch chunk c_begin, weight stages 0 (-> LDS) and 1 (stays in its register set) ----
+  if (c_begin < c_end) {
+    const int coff = c_begin * CK * 2;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) ra[q] = bload16s(rx, pgo[q], coff);
+    const int w0 = wbyte(c_begin, 0), w1 = wbyte(c_begin, 1);
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) rb[0][q] = bload16s(rw, bgo0, w0 + bgo_s(q));
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) rb[1][q] = bload16s(rw, bgo0, w1 + bgo_s(q));
+    stamp(2);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) *adst(As, plo_of(q)) = ra[q];
+#pragma unroll
+    for (int q = 0; q < NBL; ++q) *reinterpret_cast<u32x4*>(Bs + blo0 + q * BLO_STEP) = rb[0][q];
+  }
+  __syncthreads();
+  stamp(3);
+
+  // one channel chunk = NG stages, unrolled.  CP: parity of (chunk - c_begin) * NG, i.e. of the chunk's first stage
+  auto run_chunk = [&](auto cp_tag, int cc) {
+    constexpr int CP = decltype(cp_tag)::value;
+    const int apar = PDB ? ((cc - c_begin) & 1) : 0;
+    const unsigned char* Acur = As + apar * A_BYTES;
+    unsigned char* Anext = As + (apar ^ 1) * A_BYTES;
+    const bool nextc = cc + 1 < c_end;
+    const int coff_next = (cc + 1) * CK * 2;
+    // loads for a chunk / stage that does not exist go through a descriptor of zero records: they return zeros and move
+    // nothing, and the instruction stream (hence every vmcnt) stays the same
+    const __amdgpu_buffer_rsrc_t rxn = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, nextc ? p.x_bytes : 0u, 0x00020000);
+#pragma unroll
+    for (int tg = 0; tg < NG; ++tg) {
+      const int P = (CP + tg) & 1;                             // constant after unrolling
+      const unsigned char* Bcur = Bs + P * B_BYTES;
+      unsigned char* Bnext = Bs + (P ^ 1) * B_BYTES;
+      const int tg2 = (tg + 2) % NG, cc2 = cc + (tg + 2) / NG;
+      const int w2 = wbyte(cc2, tg2);
+      const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, cc2 < c_end ? p.w_bytes : 0u, 0x00020000);
+      const int sbase = 4 + 2 * min((cc - c_begin) * NG + tg, 22);
+      int aaddr[TM][TG];
+#pragma unroll
+      for (int tl = 0; tl < TG; ++tl) {
+        const int t = tg * TG + tl;
+        int toff;
+        if (KIND == KB_K3S1) { toff = (t / 3) * PW + (t % 3); }
+        else if (KIND == KB_K4S2) { const int dy = t >> 2, dx = t & 3; toff = dy * PW + (dx & 1) * (PW >> 1) + (dx >> 1); }
+        else { const int ta = t >> 1, tb2 = t & 1; toff = (py ? ta : 1 - ta) * PW + (px ? tb2 : 1 - tb2); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int prow = arow[i] + toff;
+          aaddr[i][tl] = prow * ROWB + ((lh ^ ((prow >> LGR) & (SEGS - 1))) << 4);
+        }
+      }
+      auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+        const int tl = stp / KS, ks = stp % KS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + (aaddr[i][tl] ^ (ks << 5)));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(Bcur + tl * BN * ROWB + (boffs[j] ^ (ks << 5)));
+      };
+      auto mma = [&](const bf16x8 (&a)[TM], const bf16x8 (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      };
+      // memory work of k-step slot k of this stage
+      auto side = [&](int k) {
+        if (k < HS) {
+          // weights of stage + 2 into the set this stage's weights came from
+#pragma unroll
+          for (int q = 0; q < NBL; ++q)
+            if (q * HS / NBL == k) rb[P][q] = bload16s(rw2, bgo0, w2 + bgo_s(q));
+          if (tg < ALS) {
+            const int g = tg * HS + k;
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+              if (q * AG / NPL == g) ra[q] = bload16s(rxn, pgo[q], coff_next);
+          }
+        } else {
+          const int k2 = k - HS;
+          // weights of stage + 1 (loaded during the previous stage) into the other LDS stage
+#pragma unroll
+          for (int q = 0; q < NBL; ++q)
+            if (q * HS / NBL == k2) *reinterpret_cast<u32x4*>(Bnext + blo0 + q * BLO_STEP) = rb[P ^ 1][q];
+          if (PDB && tg == NG - 1) {
+#pragma unroll
+            for (int q = 0; q < NPL; ++q)
+              if (q * HS / NPL == k2) *adst(Anext, plo_of(q)) = ra[q];
+          }
+        }
+      };
+      bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+      ldfr(0, a0, b0);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; s2 += 2) {
+        ldfr(s2 + 1, a1, b1);
+        side(s2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0);
+        side(s2 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stamp(sbase);
+      __syncthreads();
+      stamp(sbase + 1);
+      if (!PDB && tg == NG - 1 && nextc) {
+        // single patch buffer: every wave is past its last read of this chunk
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) *adst(As, plo_of(q)) = ra[q];
+        __syncthreads();
+      }
+    }
+  };
+  if ((NG & 1) == 0) {
+    for (int cc = c_begin; cc < c_end; ++cc) run_chunk(IC<0>{}, cc);
+  } else {
+    for (int cc = c_begin; cc < c_end; cc += 2) {
+      run_chunk(IC<0>{}, cc);
+      if (cc + 1 < c_end) run_chunk(IC<1>{}, cc + 1);
+    }
+  }
+
+  // ---- epilogue (as conv_bf16_kernel, 256 rows) ----
+  const bool raw = p.splitk > 1;
+  auto out_row = [&](int r) -> long long {
+    const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
+    const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
+    if (b >= p.B) return -1;
+    if (KIND == KB_TCONV) return ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+    return ((long long)b * p.Ho + oy) * p.Wo + ox;
+  };
+  if (p.cls_bias && !raw) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int tx = rr & (TW - 1), ty = (rr >> p.lgTW) & (TH - 1), tb = rr >> (p.lgTW + p.lgTH);
+        const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
+        if (b >= p.B) continue;
+        const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+        const float* bp = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) acc[i][j][r] += bp[n];
+        }
+      }
+  }
+  if (raw) {
+    float* outp = p.slab + (size_t)split * p.Mrows * p.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long row = out_row(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+        if (row < 0) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0 + wn * TN * 32 + j * 32 + l31;
+          if (n < p.N) outp[row * p.N + n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  constexpr int ERS = BN * 2 + 16;
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float mine0 = acc[i][j][2 * q], mine1 = acc[i][j][2 * q + 1];
+        const float give = odd ? mine0 : mine1;
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+        const int reg = 2 * q + (odd ? 1 : 0);
+        const int rr = wm * TM * 32 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+        const int col = wn * TN * 32 + j * 32 + (l31 & ~1);
+        const unsigned v = odd ? pack2(got, mine1) : pack2(mine0, got);
+        *reinterpret_cast<unsigned*>(smem + rr * ERS + col * 2) = v;
+      }
+  __syncthreads();
+  stamp(50);
+  {
+    constexpr int SPR = BN / 8;
+#pragma unroll
+    for (int q = 0; q < BM * SPR / NT; ++q) {
+      const int e = tid + q * NT;
+      const int rr = e / SPR, sg = e & (SPR - 1);
+      const long long row = out_row(rr);
+      const int n = n0 + sg * 8;
+      if (row >= 0 && n < p.N)
+        *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
+    }
+  }
+  stamp(51);
+  if (p.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float sv = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[i][j][r];
+          sv += v;
+          sq += v * v;
+        }
+      sv += __shfl_xor(sv, 32);
+      sq += __shfl_xor(sq, 32);
+      if (lh == 0) {
+        const int col = wn * TN * 32 + j * 32 + l31;
+        red[(0 * WAVES_M + wm) * BN + col] = sv;
+        red[(1 * WAVES_M + wm) * BN + col] = sq;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int n = n0 + tid;
+      if (n < p.N) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES_M; ++q) {
+          sv += red[(0 * WAVES_M + q) * BN + tid];
+          sq += red[(1 * WAVES_M + q) * BN + tid];
+        }
+        const int gm = phase * gridDim.x + blockIdx.x;
+        p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
+        p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
+      }
+    }
+  }
+  stamp(52);
 }
 
 // ---- weights: packed fp32 P[Tsrc][R][C] -> bf16 Wb[phase][chunk][tap][Npad][CK] -------------------------------------
@@ -512,6 +952,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 
 // ---- host-side planning ------------------------------------------------------------------------------------------
 struct BPlan {
+  int v2;   // conv_bf16_v2_kernel: 256-pixel tiles, 512 threads
   int kb, T, NG, TG, pin, dma, Ho, Wo, nphases, BN, CK, Npad;
   int lgTW, lgTH, lgTB, tilesX, tilesY, tilesB, PH, PW, npix;
   int nchunk, splitk, cps, gridM, gridN;
@@ -561,19 +1002,46 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
   S2I_REQUIRE((d->Cx % ck) == 0, "conv(bf16): %d channels do not split into chunks of %d", d->Cx, ck);
   pl->CK = ck;
   pl->Npad = s2i_cdiv(d->N, pl->BN) * pl->BN;
-  // tile of 128 output pixels: as wide as the map allows (up to 32), then rows, then images
+  // second-generation kernel (256-pixel tiles): S2I_B16_V2 = 0 never, 1 (default) where it was measured faster, 2 wherever
+  // it can run
+  static const int v2mode = getenv("S2I_B16_V2") ? atoi(getenv("S2I_B16_V2")) : 1;
+  pl->v2 = 0;
+  if (v2mode && variant == 0 && pl->BN == 128) {
+    const int ck2 = pl->kb == KB_TCONV ? 64 : 32;
+    int tw2 = pl->Wo < 32 ? pl->Wo : 32, th2 = 256 / tw2;
+    if (th2 > pl->Ho) th2 = pl->Ho;
+    const int tb2 = 256 / (tw2 * th2);
+    int ph2, pw2;
+    if (pl->kb == KB_K3S1) { ph2 = th2 + 2; pw2 = tw2 + 2; }
+    else if (pl->kb == KB_K4S2) { ph2 = 2 * th2 + 2; pw2 = 2 * tw2 + 2; }
+    else { ph2 = th2 + 1; pw2 = tw2 + 1; }
+    const int npix2 = tb2 * ph2 * pw2;
+    const int maxpix2 = pl->kb == KB_K4S2 ? 1280 : (pl->kb == KB_K3S1 ? 416 : 336);
+    bool ok = (d->Cx % ck2) == 0 && npix2 <= maxpix2;
+    if (d->stats && d->groups > 1) ok = ok && pl->kb != KB_TCONV && (d->B % d->groups) == 0 && ((d->B / d->groups) % tb2) == 0;
+    const long long blocks2 = (long long)(pl->Wo / tw2) * (pl->Ho / th2) * s2i_cdiv(d->B, tb2) * (pl->Npad / 128) * pl->nphases;
+    if (v2mode == 1) ok = ok && blocks2 >= 224;
+    if (ok) {
+      pl->v2 = 1;
+      pl->CK = ck = ck2;
+      pl->TG = pl->kb == KB_K4S2 ? 4 : (pl->kb == KB_K3S1 ? 3 : 2);
+      pl->NG = pl->T / pl->TG;
+    }
+  }
+  const int bm = pl->v2 ? 256 : 128;
+  // tile of 128 (256) output pixels: as wide as the map allows (up to 32), then rows, then images
   int tw = pl->Wo < 32 ? pl->Wo : 32;
-  int th = 128 / tw;
+  int th = bm / tw;
   if (th > pl->Ho) th = pl->Ho;
-  int tb = 128 / (tw * th);
+  int tb = bm / (tw * th);
   pl->lgTW = s2i_ilog2(tw); pl->lgTH = s2i_ilog2(th); pl->lgTB = s2i_ilog2(tb);
   pl->tilesX = pl->Wo / tw; pl->tilesY = pl->Ho / th; pl->tilesB = s2i_cdiv(d->B, tb);
   if (pl->kb == KB_K3S1) { pl->PH = th + 2; pl->PW = tw + 2; }
   else if (pl->kb == KB_K4S2) { pl->PH = 2 * th + 2; pl->PW = 2 * tw + 2; }
   else { pl->PH = th + 1; pl->PW = tw + 1; }
   pl->npix = tb * pl->PH * pl->PW;
-  if (wide_ck && pl->npix > 672 && ck == 32) { pl->CK = ck = 16; pl->TG = 8; pl->NG = 2; }   // 8 maps of 4x4 outputs per tile
-  S2I_REQUIRE(pl->npix <= (pl->kb == KB_K4S2 ? (ck == 16 ? 800 : 672) : 320),
+  if (!pl->v2 && wide_ck && pl->npix > 672 && ck == 32) { pl->CK = ck = 16; pl->TG = 8; pl->NG = 2; }   // 8 maps of 4x4 outputs per tile
+  S2I_REQUIRE(pl->v2 || pl->npix <= (pl->kb == KB_K4S2 ? (ck == 16 ? 800 : 672) : 320),
               "conv(bf16): patch of %d pixels exceeds the LDS plan", pl->npix);
   pl->gridM = pl->tilesX * pl->tilesY * pl->tilesB;
   pl->gridN = pl->Npad / pl->BN;
@@ -587,8 +1055,9 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
   }
   const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
   int splitk = 1;
-  if (blocks < 384 && pl->nchunk >= 4 && !d->nosplit) {
-    splitk = (int)(512 / blocks);
+  const int slots = pl->v2 ? 256 : 512;                 // resident blocks of the chip
+  if (blocks < slots * 3 / 4 && pl->nchunk >= 4 && !d->nosplit) {
+    splitk = (int)(slots / blocks);
     if (splitk > pl->nchunk / 2) splitk = pl->nchunk / 2;
     if (splitk > 32) splitk = 32;
     if (splitk < 1) splitk = 1;
@@ -612,6 +1081,11 @@ int bf16_stat_parts(const BPlan& pl, int groups) {
 size_t bf16_smem_bytes(const BPlan& pl) {
   const int rowb = pl.CK * 2, tg = pl.TG;
   const size_t ab = ((size_t)pl.npix * rowb + 255) & ~(size_t)255;
+  if (pl.v2) {
+    const size_t main2 = (pl.kb == KB_K4S2 ? 1 : 2) * ab + 2 * (size_t)tg * 128 * rowb + 1024;
+    const size_t epi2 = (size_t)256 * (128 * 2 + 16);
+    return main2 > epi2 ? main2 : epi2;
+  }
   const size_t main_b = ab + (size_t)tg * pl.BN * rowb * (pl.dma ? 2 : 1);
   const size_t epi = (size_t)128 * (pl.BN * 2 + 16);
   return main_b > epi ? main_b : epi;
@@ -637,8 +1111,49 @@ int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+template <int KIND, int CK, int TG, bool PDB>
+int launch_v2(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
+  const size_t shb = bf16_smem_bytes(pl);
+  S2I_REQUIRE(shb <= 160 * 1024, "conv(bf16): %zu bytes of LDS", shb);
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KIND, CK, TG, PDB>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) S2I_FAIL("conv(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
+    raised = true;
+  }
+  hipLaunchKernelGGL((conv_bf16_v2_kernel<KIND, CK, TG, PDB>), grid, dim3(512), shb, st, p);
+  return 0;
+}
+
 int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   const int kb = pl.kb, bn = pl.BN, ck = pl.CK, tg = pl.TG, pin = pl.pin;
+  if (pl.v2 && p.dbg == 32 && kb == KB_K4S2 && p.splitk == 1) {
+    // diagnostic build: stamps into a buffer of its own, written to $S2I_B16_TIMELINE after the launch
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z, bytes = nblk * 64 * sizeof(unsigned long long);
+    unsigned long long* dbuf = nullptr;
+    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess) S2I_FAIL("conv(bf16): timeline buffer");
+    (void)hipMemsetAsync(dbuf, 0, bytes, st);
+    ConvBP q = p;
+    q.slab = reinterpret_cast<float*>(dbuf);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
+    (void)hipStreamSynchronize(st);
+    const char* path = getenv("S2I_B16_TIMELINE");
+    if (path) {
+      std::vector<unsigned long long> h(nblk * 64);
+      (void)hipMemcpy(h.data(), dbuf, bytes, hipMemcpyDeviceToHost);
+      FILE* f = fopen(path, "wb");
+      if (f) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+    }
+    (void)hipFree(dbuf);
+    return 0;
+  }
+  if (pl.v2) {
+    if (kb == KB_K4S2) return launch_v2<KB_K4S2, 32, 4, false>(pl, p, grid, st);
+    if (kb == KB_K3S1) return launch_v2<KB_K3S1, 32, 3, true>(pl, p, grid, st);
+    return launch_v2<KB_TCONV, 64, 2, true>(pl, p, grid, st);
+  }
   if (pl.dma) {
     if (kb == KB_K3S1 && bn == 128 && ck == 16 && tg == 3) return launch_one<KB_K3S1, 128, 16, 3, true, true>(pl, p, grid, st);
     if (kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 4) return launch_one<KB_K4S2, 128, 16, 4, true, true>(pl, p, grid, st);
@@ -649,9 +1164,30 @@ int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st
   if (kb == K && bn == bn_ && ck == ck_ && tg == tg_ && pin == pin_) return launch_one<K, bn_, ck_, tg_, pin_>(pl, p, grid, st);
   if (p.dbg && kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 8 && pin) {
     const size_t shb = bf16_smem_bytes(pl);
-#define S2I_DBG(v) if (p.dbg == v) { hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>), grid, dim3(256), shb, st, p); return 0; }
+#define S2I_DBG(v) if (p.dbg == v) { (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>), grid, dim3(256), shb, st, p); return 0; }
     S2I_DBG(1) S2I_DBG(2) S2I_DBG(4) S2I_DBG(7) S2I_DBG(8) S2I_DBG(15) S2I_DBG(16) S2I_DBG(31) S2I_DBG(24)
 #undef S2I_DBG
+  }
+  if (p.dbg == 32 && kb == KB_K4S2 && bn == 128 && ck == 32 && tg == 4 && pin && p.splitk == 1) {
+    // diagnostic build: stamps into a buffer of its own, written to $S2I_B16_TIMELINE after the launch
+    const size_t nblk = (size_t)grid.x * grid.y * grid.z, bytes = nblk * 64 * sizeof(unsigned long long);
+    unsigned long long* dbuf = nullptr;
+    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess) S2I_FAIL("conv(bf16): timeline buffer");
+    (void)hipMemsetAsync(dbuf, 0, bytes, st);
+    ConvBP q = p;
+    q.slab = reinterpret_cast<float*>(dbuf);
+    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 32, 4, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 32, 4, true, 32>), grid, dim3(256), bf16_smem_bytes(pl), st, q);
+    (void)hipStreamSynchronize(st);
+    const char* path = getenv("S2I_B16_TIMELINE");
+    if (path) {
+      std::vector<unsigned long long> h(nblk * 64);
+      (void)hipMemcpy(h.data(), dbuf, bytes, hipMemcpyDeviceToHost);
+      FILE* f = fopen(path, "wb");
+      if (f) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+    }
+    (void)hipFree(dbuf);
+    return 0;
   }
   S2I_CASE(KB_K3S1, 128, 32, 3, true) S2I_CASE(KB_K4S2, 128, 32, 4, true)
   S2I_CASE(KB_K3S1, 128, 16, 9, true) S2I_CASE(KB_K3S1, 128, 16, 3, true) S2I_CASE(KB_K3S1, 128, 16, 3, false)
@@ -672,7 +1208,15 @@ extern "C" int s2i_conv_bf16_eligible(const s2i_conv_desc* d) {
   BPlan pl;
   const int rc = plan_bf16(d, &pl);
   if (rc) return 0;
-  return bf16_has_kernel(pl.kb, pl.BN, pl.CK) ? 1 : 0;
+  return (pl.v2 || bf16_has_kernel(pl.kb, pl.BN, pl.CK)) ? 1 : 0;
+}
+
+// identifies the arrangement of the bf16 weights the plan of this descriptor consumes (a cache key for callers: the same
+// layer at another batch size may be planned onto another kernel)
+extern "C" int s2i_conv_bf16_weight_layout(const s2i_conv_desc* d) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return -1;
+  return pl.CK | (pl.Npad << 8);
 }
 
 extern "C" size_t s2i_conv_bf16_workspace_bytes(const s2i_conv_desc* d) {

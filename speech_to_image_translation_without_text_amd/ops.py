@@ -263,7 +263,7 @@ def bf16_weight(packed, d, w_offset):
     if cache is None or cache[0] != gen:
         cache = (gen, {})
         packed._s2i_b16 = cache
-    key = (d.kind, d.wmode, d.flip, d.Cx, d.N, int(w_offset))
+    key = (d.kind, d.wmode, d.flip, d.Cx, d.N, int(w_offset), lib.s2i_conv_bf16_weight_layout(ctypes.byref(d)))
     ent = cache[1].get(key)
     if ent is None:
         old = getattr(packed, '_s2i_b16_bufs', None)
