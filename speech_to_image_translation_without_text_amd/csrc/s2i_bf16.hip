@@ -47,6 +47,7 @@ struct ConvBP {
   int N, Npad, ldy;
   int lgTW, lgTH, lgTB;
   int tilesX, tilesY;      // tiles per image along x / y (powers of two)
+  int ntiles;              // tiles in all (tilesX * tilesY * image groups)
   int PH, PW, npix;
   int nchunk, splitk, cps;
   int stats, nparts;
@@ -445,21 +446,28 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   }
 }
 
-// ---- second-generation kernel: 256 output pixels x 128 channels per block, 8 waves, everything prefetched two stages ahead --
-// What the in-kernel timeline of the 128-pixel kernel showed (tools/conv16_timeline.py): the matrix
-// loop was a quarter of a block's lifetime; the rest was the bulk issue of the next stage's loads (the CU's 64 B/clk
-// vector-memory path stalls the issuing wave, which then cannot feed the matrix pipe), waiting for loads issued only one
-// matrix phase earlier, two barriers per stage, and a prologue / epilogue per 33 MFLOP of work.  This kernel
-//   * doubles the pixel tile (the 256 KB weight stream of a block is amortised over twice the pixels: 40 % fewer bytes
-//     through the vector-memory path per FLOP),
-//   * issues every global load BETWEEN matrix instructions, a few per k-step, two stages (weights: two register sets
-//     that alternate) or a whole channel chunk (patch) before the data is needed, and moves it to LDS between matrix
-//     instructions of a later stage as well -- no bulk issue, no wait right after an issue,
-//   * keeps two weight stages (and, where the patch is small enough -- 3x3 and transposed phases -- two patch chunks) in
-//     LDS, so a stage ends with ONE barrier.
+// ---- second-generation kernel: 256 output pixels x 128 channels per tile, 8 waves, persistent over tiles ---------------
+// What the in-kernel timelines showed (tools/conv16_timeline.py).  128-pixel kernel: the matrix loop
+// was a quarter of a block's lifetime; the rest was the bulk issue of the next stage's loads (the CU's vector-memory path
+// stalls the issuing wave), waiting for loads issued one matrix phase earlier, two barriers per stage, and a prologue /
+// epilogue per 33 MFLOP.  First 256-pixel version (everything prefetched, one barrier per stage, one block per CU): the
+// steady-state stage ran the matrix pipe at 82 %, but 37 % of a block's lifetime was its prologue -- every CU of the chip
+// starts a tile at the same moment and asks HBM for its first patch chunk at once (36 MB per round: 7 us at 5 TB/s), then
+// leaves HBM idle while it computes.  This kernel therefore
+//   * keeps the 256-pixel tile (the 256 KB weight stream of a tile is amortised over twice the pixels),
+//   * issues every global load BETWEEN matrix instructions, a few per k-step: weights two stages ahead (two register
+//     sets that alternate), the next patch chunk a whole chunk ahead; the LDS stores of a later stage are interleaved too,
+//   * keeps two weight stages (and two patch chunks where the patch is small: 3x3, transposed phases) in LDS: ONE barrier
+//     per stage,
+//   * is PERSISTENT where the launcher gives it fewer blocks than tiles (stride-2 4x4): the first patch chunk and the
+//     first weight stages of the NEXT tile are prefetched during the last chunk of the current one exactly like any
+//     other next chunk, so HBM is asked for data all the time instead of in bursts, and a tile boundary costs the
+//     epilogue plus one patch store.
 // The schedule is compile-time: the stages of a channel chunk are unrolled (tap group tg, weight register set parity P),
-// so every vmcnt the compiler derives is exact.  Geometry, LDS images, swizzle, fragment maps and the epilogue are
-// those of conv_bf16_kernel.
+// so every vmcnt the compiler derives is exact; loads that must move nothing go through a descriptor of zero records.
+// Geometry, LDS images, swizzle, fragment maps and the epilogue are those of conv_bf16_kernel.  A patch segment is
+// described by its byte offset from the patch's pixel (0,0) plus four halo flags (left / right column, top / bottom
+// row) that are tested against the tile's position, so moving to the next tile costs no per-lane index arithmetic.
 template <int V> struct IC { static constexpr int value = V; };
 
 template <int KIND, int CK, int TG, bool PDB, int DBG = 0>
@@ -477,6 +485,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   static_assert(BSEG % NT == 0, "a weight stage is a whole number of 16-byte segments per thread");
   constexpr int MAXPIX = KIND == KB_K4S2 ? 1280 : (KIND == KB_K3S1 ? 416 : 336);   // plan_bf16 checks the patch against this
   constexpr int NPL = (MAXPIX * SEGS + NT - 1) / NT;
+  static_assert(NPL <= 16, "halo flags of a thread's patch segments fit two registers");
   constexpr int ALS = NG - 1;                                 // stages of a chunk that issue the next chunk's patch loads
   constexpr int AG = ALS * HS;                                // ... over this many k-step slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch (x2) | weight stage x2 | 1 KB sink]
@@ -493,18 +502,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   const int py = phase >> 1, px = phase & 1;
   const int n0 = blockIdx.y * BN;
   const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
-  const int tix = blockIdx.x & (p.tilesX - 1);
-  const int tiy = (blockIdx.x / p.tilesX) & (p.tilesY - 1);
-  const int tib = blockIdx.x / (p.tilesX * p.tilesY);
-  const int b0 = tib << p.lgTB, oy0 = tiy << p.lgTH, ox0 = tix << p.lgTW;
   const int PW = p.PW, PH = p.PH;
-  int iy0, ix0;
-  if (KIND == KB_K3S1) { iy0 = oy0 - 1; ix0 = ox0 - 1; }
-  else if (KIND == KB_K4S2) { iy0 = 2 * oy0 - 1; ix0 = 2 * ox0 - 1; }
-  else { iy0 = oy0 - (py ? 0 : 1); ix0 = ox0 - (px ? 0 : 1); }
+  const int ntiles = p.ntiles;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
   // DBG & 32 (diagnostic build of tools/conv16_timeline.py): wave 0 stamps s_memtime into a buffer of its own
   auto stamp = [&](int i) {
     if constexpr ((DBG & 32) != 0) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      if (tid == 0) {
+      if (tid == 0 && i < 64) {
         const size_t blk = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
         reinterpret_cast<unsigned long long*>(p.slab)[blk * 64 + i] = t;
       }
@@ -520,14 +520,38 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   };
   stamp(0);
 
-  // patch plan of this thread (as conv_bf16_kernel): global byte offset of segment q (chunk 0) and its swizzled LDS offset;
-  // segments beyond the patch load nothing and store to the sink.  The LDS offsets are kept in registers only where the
-  // matrix loop needs them (two patch buffers); the single-buffer form recomputes them at the chunk boundary.
+  // position of a tile: first image / output row / output column, byte offset of the patch's pixel (0,0) in x (may be
+  // negative: the halo of the first image), and which of the patch's halo sides lie outside the image
+  struct TilePos { int b0, oy0, ox0, base; unsigned edge; };
+  auto tile_pos = [&](int tile) -> TilePos {
+    TilePos t;
+    const int tix = tile & (p.tilesX - 1);
+    const int tiy = (tile / p.tilesX) & (p.tilesY - 1);
+    const int tib = tile / (p.tilesX * p.tilesY);
+    t.b0 = tib << p.lgTB; t.oy0 = tiy << p.lgTH; t.ox0 = tix << p.lgTW;
+    int iy0, ix0;
+    if (KIND == KB_K3S1) { iy0 = t.oy0 - 1; ix0 = t.ox0 - 1; }
+    else if (KIND == KB_K4S2) { iy0 = 2 * t.oy0 - 1; ix0 = 2 * t.ox0 - 1; }
+    else { iy0 = t.oy0 - (py ? 0 : 1); ix0 = t.ox0 - (px ? 0 : 1); }
+    t.base = (((t.b0 * p.H + iy0) * p.W + ix0) * p.C) * 2;
+    t.edge = (t.ox0 == 0 ? 1u : 0u) | (t.ox0 + TW == p.Wo ? 2u : 0u) | (t.oy0 == 0 ? 4u : 0u) | (t.oy0 + TH == p.Ho ? 8u : 0u);
+    return t;
+  };
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+  // patch plan of this thread: byte offset of segment q from the patch's pixel (0,0), its halo flags (4 bits per q) and
+  // its swizzled LDS offset.  The LDS offsets are kept in registers only where the matrix loop needs them (two patch
+  // buffers); the single-buffer form recomputes them at the chunk boundary.
   const int nseg = p.npix * SEGS;
   const float inv_pw = 1.0f / (float)PW, inv_ph = 1.0f / (float)PH;
-  auto patch_slot = [&](int q, int& go, int& lo) {
-    const int e = tid + q * NT;
-    go = S2I_OOB;
+  int zv = 0;   // zero the optimiser cannot see through (re-made per chunk): keeps per-lane index arithmetic that is invariant
+                // across chunks and tiles INSIDE the loops instead of hoisted into registers the matrix loop needs
+  auto patch_slot = [&](int q, int& rel, unsigned& flags, int& lo) {
+    const int e = tid + zv + q * NT;
+    rel = S2I_OOB;
+    flags = 0;
     lo = -1;
     if (e < nseg) {
       const int pix = e / SEGS, seg = e & (SEGS - 1);
@@ -535,30 +559,56 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
       const int xl = pix - rest * PW;
       const int tb = (int)(((float)rest + 0.5f) * inv_ph);
       const int yl = rest - tb * PH;
-      const int b = b0 + tb, iy = iy0 + yl, ix = ix0 + xl;
-      if (b < p.B && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) go = (((b * p.H + iy) * p.W + ix) * p.C + seg * 8) * 2;
+      rel = (((tb * p.H + yl) * p.W + xl) * p.C + seg * 8) * 2;
+      // halo sides: 3x3 and stride-2 4x4 (pad 1) have all four; a transposed-conv phase has the top row / left column
+      // when its parity is 0 and the bottom row / right column when it is 1
+      const bool hl = KIND == KB_TCONV ? px == 0 : true, hr = KIND == KB_TCONV ? px == 1 : true;
+      const bool ht = KIND == KB_TCONV ? py == 0 : true, hb = KIND == KB_TCONV ? py == 1 : true;
+      flags = (hl && xl == 0 ? 1u : 0u) | (hr && xl == PW - 1 ? 2u : 0u) | (ht && yl == 0 ? 4u : 0u) | (hb && yl == PH - 1 ? 8u : 0u);
       const int xs = KIND == KB_K4S2 ? (xl & 1) * (PW >> 1) + (xl >> 1) : xl;
       const int prow = (tb * PH + yl) * PW + xs;
       lo = prow * ROWB + ((seg ^ ((prow >> LGR) & (SEGS - 1))) << 4);
     }
   };
-  int pgo[NPL], plo[PDB ? NPL : 1];
+  // (the single-buffer form -- the stride-2 4x4, whose patch is the largest -- keeps none of this in registers: its
+  // matrix loop has no register to spare, a spilled offset comes back through a scratch load whose vmcnt wait drains the
+  // whole prefetch queue, and the dozen vector instructions per load hide behind the matrix instructions)
+  int rel[PDB ? NPL : 1], plo[PDB ? NPL : 1];
+  unsigned fw0 = 0, fw1 = 0;
+  if (PDB) {
 #pragma unroll
-  for (int q = 0; q < NPL; ++q) {
-    int go, lo;
-    patch_slot(q, go, lo);
-    pgo[q] = go;
-    if (PDB) plo[q] = lo;
+    for (int q = 0; q < NPL; ++q) {
+      int r, lo;
+      unsigned f;
+      patch_slot(q, r, f, lo);
+      rel[q] = r;
+      if (q < 8) fw0 |= f << (4 * q);
+      else fw1 |= f << (4 * (q - 8));
+      plo[q] = lo;
+    }
   }
   auto plo_of = [&](int q) -> int {
     if (PDB) return plo[q];
-    int go, lo;
-    patch_slot(q, go, lo);
+    int r, lo;
+    unsigned f;
+    patch_slot(q, r, f, lo);
     return lo;
+  };
+  // vector offset of patch segment q for a tile at (base, edge): out of range where the segment is halo outside the image
+  auto avoff = [&](int q, int base, unsigned edge) -> int {
+    if (PDB) {
+      const unsigned hit = (q < 8 ? fw0 : fw1) & (edge << (4 * (q & 7)));
+      return hit ? S2I_OOB : base + rel[q];
+    }
+    int r, lo;
+    unsigned f;
+    patch_slot(q, r, f, lo);
+    return (f & edge) ? S2I_OOB : base + r;
   };
   auto adst = [&](unsigned char* base, int lo) -> u32x4* {
     return reinterpret_cast<u32x4*>(lo >= 0 ? base + lo : smem + sink + lane * 16);
   };
+  // A fragment rows of this lane (tile row -> patch row of tap (0,0)); the same for every tile
   int arow[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -586,7 +636,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   const int wstage = TG * p.Npad * CK;                        // elements per (chunk, tap group)
   const int c_begin = split * p.cps;
   const int c_end = min(p.nchunk, c_begin + p.cps);
-  // byte base of stage (cc, tg) in the weight buffer, or out of range (the loads then return zeros and move nothing)
+  const int ncl = c_end - c_begin;                            // chunks of this block's K range
   auto wbyte = [&](int cc, int tg) -> int { return (((phase * p.nchunk + cc) * NG + tg) * wstage + n0 * CK) * 2; };
   // loads: the per-lane offset goes in the vector offset (out of range where nothing is to be loaded), the uniform part in
   // the scalar offset
@@ -596,19 +646,25 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
 
   u32x4 ra[NPL], rb[2][NBL];
   f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  zero_acc();
   stamp(1);
-  // ---- prologue: patch chunk c_begin, weight stages 0 (-> LDS) and 1 (stays in its register set) ----
-  if (c_begin < c_end) {
+
+  int tile = blockIdx.x;
+  if (tile >= ntiles || ncl <= 0) return;
+  TilePos cur = tile_pos(tile);
+  // ---- prologue: patch chunk c_begin of the first tile, weight stages 0 (-> LDS) and 1 (stays in its register set) ----
+  {
     const int coff = c_begin * CK * 2;
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) ra[q] = bload16s(rx, pgo[q], coff);
+    for (int q = 0; q < NPL; ++q) ra[q] = bload16s(rx, avoff(q, cur.base, cur.edge), coff);
     const int w0 = wbyte(c_begin, 0), w1 = wbyte(c_begin, 1);
 #pragma unroll
     for (int q = 0; q < NBL; ++q) rb[0][q] = bload16s(rw, bgo0, w0 + bgo_s(q));
@@ -623,29 +679,161 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   __syncthreads();
   stamp(3);
 
-  // one channel chunk = NG stages, unrolled.  CP: parity of (chunk - c_begin) * NG, i.e. of the chunk's first stage
-  auto run_chunk = [&](auto cp_tag, int cc) {
+  // ---- epilogue of one tile: accumulators -> y (bf16, through an LDS transpose) or fp32 slabs, BatchNorm column sums ----
+  auto epilogue = [&](const TilePos& tp, int tile_id) {
+    // the lane / wave coordinates are re-derived from a value the optimiser cannot see through, so that none of the
+    // epilogue's (tile-invariant) address arithmetic is hoisted above the tile loop into registers the matrix loop needs
+    int z = 0;
+    asm volatile("" : "+v"(z));
+    const int tid = (int)threadIdx.x + z, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const bool raw = p.splitk > 1;
+    auto out_row = [&](int r) -> long long {
+      const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
+      const int b = tp.b0 + tb, oy = tp.oy0 + ty, ox = tp.ox0 + tx;
+      if (b >= p.B) return -1;
+      if (KIND == KB_TCONV) return ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
+      return ((long long)b * p.Ho + oy) * p.Wo + ox;
+    };
+    if (p.cls_bias && !raw) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int tx = rr & (TW - 1), ty = (rr >> p.lgTW) & (TH - 1), tb = rr >> (p.lgTW + p.lgTH);
+          const int b = tp.b0 + tb, oy = tp.oy0 + ty, ox = tp.ox0 + tx;
+          if (b >= p.B) continue;
+          const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
+          const float* bp = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + l31;
+            if (n < p.N) acc[i][j][r] += bp[n];
+          }
+        }
+    }
+    if (raw) {
+      float* outp = p.slab + (size_t)split * p.Mrows * p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long long row = out_row(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
+          if (row < 0) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * TN * 32 + j * 32 + l31;
+            if (n < p.N) outp[row * p.N + n] = acc[i][j][r];
+          }
+        }
+      return;
+    }
+    constexpr int ERS = BN * 2 + 16;
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float mine0 = acc[i][j][2 * q], mine1 = acc[i][j][2 * q + 1];
+          const float give = odd ? mine0 : mine1;
+          const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+          const int reg = 2 * q + (odd ? 1 : 0);
+          const int rr = wm * TM * 32 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+          const int col = wn * TN * 32 + j * 32 + (l31 & ~1);
+          const unsigned v = odd ? pack2(got, mine1) : pack2(mine0, got);
+          *reinterpret_cast<unsigned*>(smem + rr * ERS + col * 2) = v;
+        }
+    __syncthreads();
+    stamp(50);
+    {
+      constexpr int SPR = BN / 8;
+#pragma unroll
+      for (int q = 0; q < BM * SPR / NT; ++q) {
+        const int e = tid + q * NT;
+        const int rr = e / SPR, sg = e & (SPR - 1);
+        const long long row = out_row(rr);
+        const int n = n0 + sg * 8;
+        if (row >= 0 && n < p.N)
+          *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
+      }
+    }
+    stamp(51);
+    if (p.stats) {
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float sv = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = acc[i][j][r];
+            sv += v;
+            sq += v * v;
+          }
+        sv += __shfl_xor(sv, 32);
+        sq += __shfl_xor(sq, 32);
+        if (lh == 0) {
+          const int col = wn * TN * 32 + j * 32 + l31;
+          red[(0 * WAVES_M + wm) * BN + col] = sv;
+          red[(1 * WAVES_M + wm) * BN + col] = sq;
+        }
+      }
+      __syncthreads();
+      if (tid < BN) {
+        const int n = n0 + tid;
+        if (n < p.N) {
+          float sv = 0.f, sq = 0.f;
+#pragma unroll
+          for (int q = 0; q < WAVES_M; ++q) {
+            sv += red[(0 * WAVES_M + q) * BN + tid];
+            sq += red[(1 * WAVES_M + q) * BN + tid];
+          }
+          const int gm = phase * ntiles + tile_id;
+          p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
+          p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
+        }
+      }
+    }
+    stamp(52);
+  };
+
+  // one channel chunk = NG stages, unrolled.  CP: parity of the chunk's first stage among the block's stages.
+  // ci: index of the chunk inside [c_begin, c_end).  The chunk AFTER the last one of a tile is the first chunk of the
+  // block's next tile (patch and weights alike); after the last tile nothing follows and the loads move nothing.
+  int apar = 0;                                               // patch buffer in use (two-buffer form)
+  auto run_chunk = [&](auto cp_tag, int ci, const TilePos& nxt, bool more_tiles) {
     constexpr int CP = decltype(cp_tag)::value;
-    const int apar = PDB ? ((cc - c_begin) & 1) : 0;
+    if (!PDB) asm volatile("" : "+v"(zv));
+    const int cc = c_begin + ci;
+    const bool last_chunk = ci + 1 == ncl;
+    const bool nextc = !last_chunk || more_tiles;             // a patch chunk follows this one
+    const int coff_next = (last_chunk ? c_begin : cc + 1) * CK * 2;
+    const int nbase = last_chunk ? nxt.base : cur.base;
+    const unsigned nedge = last_chunk ? nxt.edge : cur.edge;
     const unsigned char* Acur = As + apar * A_BYTES;
     unsigned char* Anext = As + (apar ^ 1) * A_BYTES;
-    const bool nextc = cc + 1 < c_end;
-    const int coff_next = (cc + 1) * CK * 2;
-    // loads for a chunk / stage that does not exist go through a descriptor of zero records: they return zeros and move
-    // nothing, and the instruction stream (hence every vmcnt) stays the same
     const __amdgpu_buffer_rsrc_t rxn = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, nextc ? p.x_bytes : 0u, 0x00020000);
 #pragma unroll
     for (int tg = 0; tg < NG; ++tg) {
       const int P = (CP + tg) & 1;                             // constant after unrolling
       const unsigned char* Bcur = Bs + P * B_BYTES;
       unsigned char* Bnext = Bs + (P ^ 1) * B_BYTES;
-      const int tg2 = (tg + 2) % NG, cc2 = cc + (tg + 2) / NG;
-      const int w2 = wbyte(cc2, tg2);
-      const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, cc2 < c_end ? p.w_bytes : 0u, 0x00020000);
-      const int sbase = 4 + 2 * min((cc - c_begin) * NG + tg, 22);
-      int aaddr[TM][TG];
-#pragma unroll
-      for (int tl = 0; tl < TG; ++tl) {
+      // the stage two ahead: (chunk, tap group), wrapping into the next tile
+      const int tg2 = (tg + 2) % NG;
+      int ci2 = ci + (tg + 2) / NG;
+      bool have2 = true;
+      if (ci2 >= ncl) { ci2 -= ncl; have2 = more_tiles; }
+      const int w2 = wbyte(c_begin + ci2, tg2);
+      const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, have2 ? p.w_bytes : 0u, 0x00020000);
+      // LDS byte offset of this lane's A fragment rows for one tap (k-step 0; k-step ks is that XOR (ks << 5))
+      int aad0[TM], aad1[TM];
+      auto tap_addr = [&](int tl, int (&aad)[TM]) {
         const int t = tg * TG + tl;
         int toff;
         if (KIND == KB_K3S1) { toff = (t / 3) * PW + (t % 3); }
@@ -653,14 +841,17 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
         else { const int ta = t >> 1, tb2 = t & 1; toff = (py ? ta : 1 - ta) * PW + (px ? tb2 : 1 - tb2); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int prow = arow[i] + toff;
-          aaddr[i][tl] = prow * ROWB + ((lh ^ ((prow >> LGR) & (SEGS - 1))) << 4);
+          const int prow = arow[i] + zv + toff;
+          aad[i] = prow * ROWB + ((lh ^ ((prow >> LGR) & (SEGS - 1))) << 4);
         }
-      }
-      auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN]) {
+      };
+      // k-step stp reads tap stp / KS; consecutive k-steps alternate between the two address sets only when a tap is a
+      // single k-step (never: KS >= 2), so one set per fragment register set suffices
+      auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN], int (&aad)[TM]) {
         const int tl = stp / KS, ks = stp % KS;
+        if (ks < 2) tap_addr(tl, aad);            // the first use of this tap by this register set
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + (aaddr[i][tl] ^ (ks << 5)));
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + (aad[i] ^ (ks << 5)));
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           b[j] = *reinterpret_cast<const bf16x8*>(Bcur + tl * BN * ROWB + (boffs[j] ^ (ks << 5)));
@@ -682,7 +873,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
             const int g = tg * HS + k;
 #pragma unroll
             for (int q = 0; q < NPL; ++q)
-              if (q * AG / NPL == g) ra[q] = bload16s(rxn, pgo[q], coff_next);
+              if (q * AG / NPL == g) ra[q] = bload16s(rxn, avoff(q, nbase, nedge), coff_next);
           }
         } else {
           const int k2 = k - HS;
@@ -698,154 +889,68 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
         }
       };
       bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-      ldfr(0, a0, b0);
+      ldfr(0, a0, b0, aad0);
 #pragma unroll
       for (int s2 = 0; s2 < NS; s2 += 2) {
-        ldfr(s2 + 1, a1, b1);
+        ldfr(s2 + 1, a1, b1, aad1);
         side(s2);
         __builtin_amdgcn_sched_barrier(0);
         mma(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
-        if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0);
+        if (s2 + 2 < NS) ldfr(s2 + 2, a0, b0, aad0);
         side(s2 + 1);
         __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      stamp(sbase);
+      if constexpr ((DBG & 32) != 0) stamp(4 + 2 * min(ci * NG + tg, 22));
       __syncthreads();
-      stamp(sbase + 1);
-      if (!PDB && tg == NG - 1 && nextc) {
-        // single patch buffer: every wave is past its last read of this chunk
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) *adst(As, plo_of(q)) = ra[q];
-        __syncthreads();
-      }
+      if constexpr ((DBG & 32) != 0) stamp(5 + 2 * min(ci * NG + tg, 22));
     }
+    if (PDB) apar ^= 1;
   };
-  if ((NG & 1) == 0) {
-    for (int cc = c_begin; cc < c_end; ++cc) run_chunk(IC<0>{}, cc);
-  } else {
-    for (int cc = c_begin; cc < c_end; cc += 2) {
-      run_chunk(IC<0>{}, cc);
-      if (cc + 1 < c_end) run_chunk(IC<1>{}, cc + 1);
-    }
-  }
 
-  // ---- epilogue (as conv_bf16_kernel, 256 rows) ----
-  const bool raw = p.splitk > 1;
-  auto out_row = [&](int r) -> long long {
-    const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
-    const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
-    if (b >= p.B) return -1;
-    if (KIND == KB_TCONV) return ((long long)b * (2 * p.Ho) + 2 * oy + py) * (2 * p.Wo) + 2 * ox + px;
-    return ((long long)b * p.Ho + oy) * p.Wo + ox;
+  auto chunk_boundary = [&](int ci) {
+    if (!PDB && ci + 1 < ncl) {
+      // single patch buffer: every wave is past its last read of this chunk
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) *adst(As, plo_of(q)) = ra[q];
+      __syncthreads();
+    }
   };
-  if (p.cls_bias && !raw) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int tx = rr & (TW - 1), ty = (rr >> p.lgTW) & (TH - 1), tb = rr >> (p.lgTW + p.lgTH);
-        const int b = b0 + tb, oy = oy0 + ty, ox = ox0 + tx;
-        if (b >= p.B) continue;
-        const int cls = 3 * (oy == 0 ? 0 : (oy == p.Ho - 1 ? 2 : 1)) + (ox == 0 ? 0 : (ox == p.Wo - 1 ? 2 : 1));
-        const float* bp = p.cls_bias + ((size_t)b * 9 + cls) * p.N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * TN * 32 + j * 32 + l31;
-          if (n < p.N) acc[i][j][r] += bp[n];
+  for (;;) {
+    const int ntile = tile + (int)gridDim.x;
+    const bool more_tiles = !PDB && ntile < ntiles;           // the two-patch-buffer forms are launched one block per tile
+    const TilePos nxt = tile_pos(more_tiles ? ntile : tile);
+    if constexpr ((NG & 1) == 0) {
+      for (int ci = 0; ci < ncl; ++ci) {
+        run_chunk(IC<0>{}, ci, nxt, more_tiles);
+        chunk_boundary(ci);
+      }
+    } else {
+      // odd number of stages per chunk: the weight register sets swap roles from one chunk to the next
+      static_assert((NG & 1) == 0 || PDB, "the persistent form needs an even number of stages per tile");
+      for (int ci = 0; ci < ncl; ci += 2) {
+        run_chunk(IC<0>{}, ci, nxt, more_tiles);
+        chunk_boundary(ci);
+        if (ci + 1 < ncl) {
+          run_chunk(IC<1>{}, ci + 1, nxt, more_tiles);
+          chunk_boundary(ci + 1);
         }
       }
-  }
-  if (raw) {
-    float* outp = p.slab + (size_t)split * p.Mrows * p.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long long row = out_row(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh);
-        if (row < 0) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = n0 + wn * TN * 32 + j * 32 + l31;
-          if (n < p.N) outp[row * p.N + n] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-  constexpr int ERS = BN * 2 + 16;
-  const bool odd = lane & 1;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const float mine0 = acc[i][j][2 * q], mine1 = acc[i][j][2 * q + 1];
-        const float give = odd ? mine0 : mine1;
-        const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-        const int reg = 2 * q + (odd ? 1 : 0);
-        const int rr = wm * TM * 32 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
-        const int col = wn * TN * 32 + j * 32 + (l31 & ~1);
-        const unsigned v = odd ? pack2(got, mine1) : pack2(mine0, got);
-        *reinterpret_cast<unsigned*>(smem + rr * ERS + col * 2) = v;
-      }
-  __syncthreads();
-  stamp(50);
-  {
-    constexpr int SPR = BN / 8;
-#pragma unroll
-    for (int q = 0; q < BM * SPR / NT; ++q) {
-      const int e = tid + q * NT;
-      const int rr = e / SPR, sg = e & (SPR - 1);
-      const long long row = out_row(rr);
-      const int n = n0 + sg * 8;
-      if (row >= 0 && n < p.N)
-        *reinterpret_cast<u32x4*>(p.y + row * p.ldy + n) = *reinterpret_cast<const u32x4*>(smem + rr * ERS + sg * 16);
     }
-  }
-  stamp(51);
-  if (p.stats) {
+    // every wave is past its last LDS read of this tile: the patch region is free for the epilogue's transpose.  The next
+    // tile's first patch chunk is still in registers and its first weight stages sit behind the patch region.
+    epilogue(cur, tile);
+    if (!more_tiles) break;
+    zero_acc();
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem);  // [2][WAVES_M][BN]
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      float sv = 0.f, sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[i][j][r];
-          sv += v;
-          sq += v * v;
-        }
-      sv += __shfl_xor(sv, 32);
-      sq += __shfl_xor(sq, 32);
-      if (lh == 0) {
-        const int col = wn * TN * 32 + j * 32 + l31;
-        red[(0 * WAVES_M + wm) * BN + col] = sv;
-        red[(1 * WAVES_M + wm) * BN + col] = sq;
-      }
-    }
+    for (int q = 0; q < NPL; ++q) *adst(As, plo_of(q)) = ra[q];
     __syncthreads();
-    if (tid < BN) {
-      const int n = n0 + tid;
-      if (n < p.N) {
-        float sv = 0.f, sq = 0.f;
-#pragma unroll
-        for (int q = 0; q < WAVES_M; ++q) {
-          sv += red[(0 * WAVES_M + q) * BN + tid];
-          sq += red[(1 * WAVES_M + q) * BN + tid];
-        }
-        const int gm = phase * gridDim.x + blockIdx.x;
-        p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
-        p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
-      }
-    }
+    tile = ntile;
+    cur = nxt;
   }
-  stamp(52);
 }
 
 // ---- weights: packed fp32 P[Tsrc][R][C] -> bf16 Wb[phase][chunk][tap][Npad][CK] -------------------------------------
@@ -1004,7 +1109,7 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
   pl->Npad = s2i_cdiv(d->N, pl->BN) * pl->BN;
   // second-generation kernel (256-pixel tiles): S2I_B16_V2 = 0 never, 1 (default) where it was measured faster, 2 wherever
   // it can run
-  static const int v2mode = getenv("S2I_B16_V2") ? atoi(getenv("S2I_B16_V2")) : 1;
+  const int v2mode = getenv("S2I_B16_V2") ? atoi(getenv("S2I_B16_V2")) : 1;   // read per call: tests switch it
   pl->v2 = 0;
   if (v2mode && variant == 0 && pl->BN == 128) {
     const int ck2 = pl->kb == KB_TCONV ? 64 : 32;
@@ -1111,10 +1216,26 @@ int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+// blocks along x for the second-generation kernel: persistent (one block per CU looping over its tiles) where the kernel
+// supports it -- single patch buffer, no split-K, and a patch region large enough for the epilogue's transpose
+int v2_grid_x(const BPlan& pl) {
+  const int pers = getenv("S2I_B16_PERSISTENT") ? atoi(getenv("S2I_B16_PERSISTENT")) : 1;
+  const size_t ab = ((size_t)pl.npix * pl.CK * 2 + 255) & ~(size_t)255;
+  if (!pers || pl.kb != KB_K4S2 || pl.splitk != 1 || ab < (size_t)256 * (128 * 2 + 16)) return pl.gridM;
+  int nblk = (pers > 1 ? pers : 256) / (pl.gridN * pl.nphases);   // S2I_B16_PERSISTENT > 1: that many block slots (tests)
+  if (nblk < 1) nblk = 1;
+  if (pl.gridM <= nblk) return pl.gridM;
+  // a block walks ceil(gridM / nblk) tiles: persistent only where that rounding costs little (measured: 144 tiles over
+  // 64 slots -- 3 rounds for 2.25 rounds of work -- lost what the prefetch across tiles gained)
+  if (pers == 1 && (pl.gridM % nblk) != 0 && pl.gridM < 6 * nblk) return pl.gridM;
+  return nblk;
+}
+
 template <int KIND, int CK, int TG, bool PDB>
 int launch_v2(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   const size_t shb = bf16_smem_bytes(pl);
   S2I_REQUIRE(shb <= 160 * 1024, "conv(bf16): %zu bytes of LDS", shb);
+  grid.x = v2_grid_x(pl);
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KIND, CK, TG, PDB>,
@@ -1130,6 +1251,7 @@ int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st
   const int kb = pl.kb, bn = pl.BN, ck = pl.CK, tg = pl.TG, pin = pl.pin;
   if (pl.v2 && p.dbg == 32 && kb == KB_K4S2 && p.splitk == 1) {
     // diagnostic build: stamps into a buffer of its own, written to $S2I_B16_TIMELINE after the launch
+    grid.x = v2_grid_x(pl);
     const size_t nblk = (size_t)grid.x * grid.y * grid.z, bytes = nblk * 64 * sizeof(unsigned long long);
     unsigned long long* dbuf = nullptr;
     if (hipMalloc((void**)&dbuf, bytes) != hipSuccess) S2I_FAIL("conv(bf16): timeline buffer");
@@ -1268,6 +1390,7 @@ extern "C" int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned shor
   p.B = d->B; p.H = d->H; p.W = d->W; p.C = d->Cx; p.Ho = pl.Ho; p.Wo = pl.Wo;
   p.N = d->N; p.Npad = pl.Npad; p.ldy = d->ldy;
   p.lgTW = pl.lgTW; p.lgTH = pl.lgTH; p.lgTB = pl.lgTB; p.tilesX = pl.tilesX; p.tilesY = pl.tilesY;
+  p.ntiles = pl.gridM;
   p.PH = pl.PH; p.PW = pl.PW; p.npix = pl.npix;
   p.nchunk = pl.nchunk; p.splitk = pl.splitk; p.cps = pl.cps;
   p.stats = d->stats; p.nparts = pl.gridM * pl.nphases; p.Mrows = pl.Mrows;

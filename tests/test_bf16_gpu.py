@@ -77,9 +77,38 @@ CONV_CASES = [
 ]
 
 
+# cases for the 256-pixel second-generation kernel (S2I_B16_V2=2: wherever it can run; S2I_B16_PERSISTENT=4: four block
+# slots, so that a block walks several tiles)
+V2_CASES = [
+    ("k4s2", 3, 64, 64, 128),         # 12 tiles of 8x32 outputs over 4 persistent blocks: top / bottom halo rows, 2 chunks
+    ("k4s2", 2, 128, 32, 128),        # two tiles across a row (left / right halo columns), ONE channel chunk
+    ("k4s2", 5, 32, 128, 256),        # one 16x16 map per tile, two channel blocks, 4 chunks, odd tile count
+    ("k4s2", 2, 64, 64, 128),
+    ("k3s1", 2, 64, 64, 128),         # two patch buffers, 3 stages per chunk (register sets swap roles per chunk)
+    ("k3s1", 5, 8, 96, 256),          # 4 images per tile, ragged batch, 3 chunks (odd)
+    ("k3s1", 3, 16, 32, 192),         # one chunk; 192 channels = 1.5 channel blocks
+    ("up", 2, 32, 64, 128),           # transposed phases: halo sides depend on the phase parity; one chunk of 64
+    ("up", 3, 16, 128, 128),          # 2 chunks
+    ("up", 5, 8, 192, 256),           # 4 images per tile, ragged, 3 chunks
+]
+
+
+@pytest.mark.parametrize("case", V2_CASES, ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16_conv_second_generation_kernels(gpu, case, monkeypatch):
+    """The same check through conv_bf16_v2_kernel, forced wherever it is eligible, with few enough block slots that the
+    persistent form walks several tiles per block."""
+    monkeypatch.setenv("S2I_B16_V2", "2")
+    monkeypatch.setenv("S2I_B16_PERSISTENT", "4")
+    _conv_case(gpu, case)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_bf16_conv_kernels_against_fp32_on_rounded_operands(gpu, case):
     """Forward, input gradient and weight gradient of one convolution through the bf16 kernels."""
+    _conv_case(gpu, case)
+
+
+def _conv_case(gpu, case):
     from speech_to_image_translation_without_text_amd import ops
     from speech_to_image_translation_without_text_amd._lib import PACK_PLAIN, PACK_UPFOLD
     kind, B, H, Cin, Cout = case
