@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
 // row) that are tested against the tile's position, so moving to the next tile costs no per-lane index arithmetic.
 template <int V> struct IC { static constexpr int value = V; };
 
-template <int KIND, int CK, int TG, bool PDB, int DBG = 0>
+// PWC != 0: the patch is PWC pixels wide (compile time) and its LDS rows are padded to 80 bytes instead of XOR-swizzled: a
+// fragment address is then lane base + constant, i.e. the matrix loop spends NO vector instruction on addresses (with
+// one k-step of read-ahead, a dependent address chain in front of every read starved the matrix pipe: +40 % per stage).
+// 80 = 5 x 16 bytes and 5 is odd, so the 16 lanes of a ds_read_b128 group (consecutive patch rows) hit 16 distinct
+// 16-byte bank groups.
+template <int KIND, int CK, int TG, bool PDB, int DBG = 0, int PWC = 0>
 __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   constexpr int BN = 128, BM = 256, NT = 512;
   constexpr int T = KIND == KB_K3S1 ? 9 : (KIND == KB_K4S2 ? 16 : 4);
@@ -478,6 +483,9 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   static_assert(NG * TG == T && NG >= 2, "tap groups must tile the taps, at least two stages per channel chunk");
   constexpr int WAVES_N = 2, WAVES_M = 4, TM = 2, TN = 2;
   constexpr int SEGS = CK / 8, ROWB = CK * 2;
+  constexpr bool PADA = PWC != 0;
+  constexpr int AROWB = PADA ? ROWB + 16 : ROWB;              // bytes per patch row in LDS
+  static_assert(!PADA || (KIND == KB_K4S2 && CK == 32), "padded patch rows: stride-2 4x4 with 32-channel chunks");
   constexpr int LGR = SEGS == 2 ? 3 : (SEGS == 4 ? 2 : 1);
   constexpr int KS = CK / 16, NS = TG * KS, HS = NS / 2;      // k-steps per stage; the first HS issue loads, the rest store
   static_assert((NS % 2) == 0, "even number of k-steps per stage");
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   constexpr int ALS = NG - 1;                                 // stages of a chunk that issue the next chunk's patch loads
   constexpr int AG = ALS * HS;                                // ... over this many k-step slots
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch (x2) | weight stage x2 | 1 KB sink]
-  const int A_BYTES = (p.npix * ROWB + 255) & ~255;
+  const int A_BYTES = (p.npix * AROWB + 255) & ~255;
   unsigned char* As = smem;
   unsigned char* Bs = smem + (PDB ? 2 : 1) * A_BYTES;
   const int sink = (PDB ? 2 : 1) * A_BYTES + 2 * B_BYTES;     // lanes without a patch segment store here (no exec masks)
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   const int py = phase >> 1, px = phase & 1;
   const int n0 = blockIdx.y * BN;
   const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
-  const int PW = p.PW, PH = p.PH;
+  const int PW = PADA ? PWC : p.PW, PH = p.PH;
   const int ntiles = p.ntiles;
 
   // DBG & 32 (diagnostic build of tools/conv16_timeline.py): wave 0 stamps s_memtime into a buffer of its own
@@ -567,25 +575,23 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
       flags = (hl && xl == 0 ? 1u : 0u) | (hr && xl == PW - 1 ? 2u : 0u) | (ht && yl == 0 ? 4u : 0u) | (hb && yl == PH - 1 ? 8u : 0u);
       const int xs = KIND == KB_K4S2 ? (xl & 1) * (PW >> 1) + (xl >> 1) : xl;
       const int prow = (tb * PH + yl) * PW + xs;
-      lo = prow * ROWB + ((seg ^ ((prow >> LGR) & (SEGS - 1))) << 4);
+      lo = PADA ? prow * AROWB + seg * 16 : prow * ROWB + ((seg ^ ((prow >> LGR) & (SEGS - 1))) << 4);
     }
   };
-  // (the single-buffer form -- the stride-2 4x4, whose patch is the largest -- keeps none of this in registers: its
-  // matrix loop has no register to spare, a spilled offset comes back through a scratch load whose vmcnt wait drains the
-  // whole prefetch queue, and the dozen vector instructions per load hide behind the matrix instructions)
-  int rel[PDB ? NPL : 1], plo[PDB ? NPL : 1];
+  // (the single-buffer form -- the stride-2 4x4, whose patch is the largest -- recomputes the LDS offsets at the chunk
+  // boundary instead of keeping them: its matrix loop has no register to spare, and a spilled value comes back through a
+  // scratch load whose vmcnt wait drains the whole prefetch queue)
+  int rel[NPL], plo[PDB ? NPL : 1];
   unsigned fw0 = 0, fw1 = 0;
-  if (PDB) {
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-      int r, lo;
-      unsigned f;
-      patch_slot(q, r, f, lo);
-      rel[q] = r;
-      if (q < 8) fw0 |= f << (4 * q);
-      else fw1 |= f << (4 * (q - 8));
-      plo[q] = lo;
-    }
+  for (int q = 0; q < NPL; ++q) {
+    int r, lo;
+    unsigned f;
+    patch_slot(q, r, f, lo);
+    rel[q] = r;
+    if (q < 8) fw0 |= f << (4 * q);
+    else fw1 |= f << (4 * (q - 8));
+    if (PDB) plo[q] = lo;
   }
   auto plo_of = [&](int q) -> int {
     if (PDB) return plo[q];
@@ -596,14 +602,8 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
   };
   // vector offset of patch segment q for a tile at (base, edge): out of range where the segment is halo outside the image
   auto avoff = [&](int q, int base, unsigned edge) -> int {
-    if (PDB) {
-      const unsigned hit = (q < 8 ? fw0 : fw1) & (edge << (4 * (q & 7)));
-      return hit ? S2I_OOB : base + rel[q];
-    }
-    int r, lo;
-    unsigned f;
-    patch_slot(q, r, f, lo);
-    return (f & edge) ? S2I_OOB : base + r;
+    const unsigned hit = (q < 8 ? fw0 : fw1) & (edge << (4 * (q & 7)));
+    return hit ? S2I_OOB : base + rel[q];
   };
   auto adst = [&](unsigned char* base, int lo) -> u32x4* {
     return reinterpret_cast<u32x4*>(lo >= 0 ? base + lo : smem + sink + lane * 16);
@@ -615,6 +615,7 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
     const int r = wm * TM * 32 + i * 32 + l31;
     const int tx = r & (TW - 1), ty = (r >> p.lgTW) & (TH - 1), tb = r >> (p.lgTW + p.lgTH);
     arow[i] = (tb * PH + (KIND == KB_K4S2 ? 2 * ty : ty)) * PW + tx;
+    if (PADA) arow[i] = arow[i] * AROWB + lh * 16;           // padded rows: the lane's byte base, taps and k-steps add constants
   }
   int boffs[TN];
 #pragma unroll
@@ -849,9 +850,16 @@ __global__ __launch_bounds__(512, 1) void conv_bf16_v2_kernel(ConvBP p) {
       // single k-step (never: KS >= 2), so one set per fragment register set suffices
       auto ldfr = [&](int stp, bf16x8 (&a)[TM], bf16x8 (&b)[TN], int (&aad)[TM]) {
         const int tl = stp / KS, ks = stp % KS;
-        if (ks < 2) tap_addr(tl, aad);            // the first use of this tap by this register set
+        if constexpr (PADA) {
+          const int t = tg * TG + tl, dy = t >> 2, dx = t & 3;
+          const int cst = (dy * PWC + (dx & 1) * (PWC >> 1) + (dx >> 1)) * AROWB + ks * 32;   // constant after unrolling
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + (aad[i] ^ (ks << 5)));
+          for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + arow[i] + cst);
+        } else {
+          if (ks < 2) tap_addr(tl, aad);            // the first use of this tap by this register set
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Acur + (aad[i] ^ (ks << 5)));
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           b[j] = *reinterpret_cast<const bf16x8*>(Bcur + tl * BN * ROWB + (boffs[j] ^ (ks << 5)));
@@ -1183,10 +1191,14 @@ int bf16_stat_parts(const BPlan& pl, int groups) {
   return pl.gridM * pl.nphases;
 }
 
+// the 66-pixel-wide stride-2 patch (32-column tiles) takes the padded-row instantiation
+bool v2_padded(const BPlan& pl) { return pl.v2 && pl.kb == KB_K4S2 && pl.PW == 66 && pl.CK == 32; }
+
 size_t bf16_smem_bytes(const BPlan& pl) {
   const int rowb = pl.CK * 2, tg = pl.TG;
-  const size_t ab = ((size_t)pl.npix * rowb + 255) & ~(size_t)255;
+  size_t ab = ((size_t)pl.npix * rowb + 255) & ~(size_t)255;
   if (pl.v2) {
+    if (v2_padded(pl)) ab = ((size_t)pl.npix * (rowb + 16) + 255) & ~(size_t)255;
     const size_t main2 = (pl.kb == KB_K4S2 ? 1 : 2) * ab + 2 * (size_t)tg * 128 * rowb + 1024;
     const size_t epi2 = (size_t)256 * (128 * 2 + 16);
     return main2 > epi2 ? main2 : epi2;
@@ -1220,7 +1232,7 @@ int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
 // supports it -- single patch buffer, no split-K, and a patch region large enough for the epilogue's transpose
 int v2_grid_x(const BPlan& pl) {
   const int pers = getenv("S2I_B16_PERSISTENT") ? atoi(getenv("S2I_B16_PERSISTENT")) : 1;
-  const size_t ab = ((size_t)pl.npix * pl.CK * 2 + 255) & ~(size_t)255;
+  const size_t ab = ((size_t)pl.npix * (pl.CK * 2 + (v2_padded(pl) ? 16 : 0)) + 255) & ~(size_t)255;
   if (!pers || pl.kb != KB_K4S2 || pl.splitk != 1 || ab < (size_t)256 * (128 * 2 + 16)) return pl.gridM;
   int nblk = (pers > 1 ? pers : 256) / (pl.gridN * pl.nphases);   // S2I_B16_PERSISTENT > 1: that many block slots (tests)
   if (nblk < 1) nblk = 1;
@@ -1231,19 +1243,19 @@ int v2_grid_x(const BPlan& pl) {
   return nblk;
 }
 
-template <int KIND, int CK, int TG, bool PDB>
+template <int KIND, int CK, int TG, bool PDB, int PWC = 0>
 int launch_v2(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   const size_t shb = bf16_smem_bytes(pl);
   S2I_REQUIRE(shb <= 160 * 1024, "conv(bf16): %zu bytes of LDS", shb);
   grid.x = v2_grid_x(pl);
   static bool raised = false;
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KIND, CK, TG, PDB>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KIND, CK, TG, PDB, 0, PWC>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) S2I_FAIL("conv(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
     raised = true;
   }
-  hipLaunchKernelGGL((conv_bf16_v2_kernel<KIND, CK, TG, PDB>), grid, dim3(512), shb, st, p);
+  hipLaunchKernelGGL((conv_bf16_v2_kernel<KIND, CK, TG, PDB, 0, PWC>), grid, dim3(512), shb, st, p);
   return 0;
 }
 
@@ -1258,8 +1270,13 @@ int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st
     (void)hipMemsetAsync(dbuf, 0, bytes, st);
     ConvBP q = p;
     q.slab = reinterpret_cast<float*>(dbuf);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
+    if (v2_padded(pl)) {
+      (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32, 66>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32, 66>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
+    }
     (void)hipStreamSynchronize(st);
     const char* path = getenv("S2I_B16_TIMELINE");
     if (path) {
@@ -1272,6 +1289,7 @@ int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st
     return 0;
   }
   if (pl.v2) {
+    if (kb == KB_K4S2 && v2_padded(pl)) return launch_v2<KB_K4S2, 32, 4, false, 66>(pl, p, grid, st);
     if (kb == KB_K4S2) return launch_v2<KB_K4S2, 32, 4, false>(pl, p, grid, st);
     if (kb == KB_K3S1) return launch_v2<KB_K3S1, 32, 3, true>(pl, p, grid, st);
     return launch_v2<KB_TCONV, 64, 2, true>(pl, p, grid, st);
