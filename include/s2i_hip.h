@@ -181,6 +181,18 @@ size_t s2i_conv_bf16_weight_elems(const s2i_conv_desc* d);
 int    s2i_conv_bf16_weight_layout(const s2i_conv_desc* d);
 int s2i_pack_conv_weight_bf16(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
                               void* stream);
+/* The bf16 copies of a whole network in one launch (after the fused Adam step).  s2i_pack16_item_fill (host only, no
+ * launch) fills the item of one (descriptor, packed fp32 source, destination) exactly as s2i_pack_conv_weight_bf16 would
+ * pack it and returns its block count (-1 on error); the caller assigns block0 = running sum of the counts and uploads the
+ * array. */
+typedef struct s2i_pack16_item {
+  const float* P;        /* packed fp32 source (P[t][R][C], possibly offset to a row inside a tap) */
+  unsigned short* out;   /* Wb[phase][chunk][tap][Npad][CK] */
+  int R, C, kind, flip, transpose, T, nphase, Nn, Npad, Kk, CK, gx, gy, block0;
+} s2i_pack16_item;
+int s2i_pack16_item_fill(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
+                         s2i_pack16_item* item);
+int s2i_pack_conv_weights_bf16_batched(const s2i_pack16_item* items_dev, int n, int total_blocks, void* stream);
 int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned short* x, const unsigned short* w,
                           const float* cls_bias, unsigned short* y, float* part, void* ws, size_t ws_bytes,
                           void* stream);

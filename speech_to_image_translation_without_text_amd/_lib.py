@@ -38,6 +38,11 @@ class PackItem(ctypes.Structure):
                                                                                "block0")]
 
 
+class Pack16Item(ctypes.Structure):
+    _fields_ = [("P", c_void_p), ("out", c_void_p)] + [(n, c_int) for n in (
+        "R", "C", "kind", "flip", "transpose", "T", "nphase", "Nn", "Npad", "Kk", "CK", "gx", "gy", "block0")]
+
+
 P = c_void_p
 _SIGNATURES = {
     "s2i_last_error": (ctypes.c_char_p, []),
@@ -57,6 +62,8 @@ _SIGNATURES = {
     "s2i_conv_bf16_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_bf16_weight_elems": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_bf16_weight_layout": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "s2i_pack16_item_fill": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, c_int, P, ctypes.POINTER(Pack16Item)]),
+    "s2i_pack_conv_weights_bf16_batched": (c_int, [P, c_int, c_int, P]),
     "s2i_pack_conv_weight_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, c_int, P, P]),
     "s2i_conv_forward_bf16": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
     "s2i_conv_forward_dt": (c_int, [ctypes.POINTER(ConvDesc), P, c_int, P, P, P, P, P, c_int, P, P, c_size_t, P]),

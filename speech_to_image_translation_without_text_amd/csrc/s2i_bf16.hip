@@ -976,15 +976,13 @@ __device__ __forceinline__ int src_tap(int kind, int flip, int T, int t, int pha
   return flip ? (T - 1 - t) : t;
 }
 
-__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ P, unsigned short* __restrict__ out, int R,
-                                                        int C, int kind, int flip, int transpose, int T, int nphase,
-                                                        int Nn, int Npad, int Kk, int CK) {
-  __shared__ float tile[32][33];
-  const int zt = blockIdx.z;               // phase * T + t
-  const int phase = zt / T, t = zt - phase * T;
+__device__ __forceinline__ void pack_bf16_block(const float* __restrict__ P, unsigned short* __restrict__ out, int R, int C,
+                                                int kind, int flip, int transpose, int T, int Nn, int Npad, int Kk,
+                                                int CK, int bx, int by, int zt, float (&tile)[32][33]) {
+  const int phase = zt / T, t = zt - phase * T;   // zt = phase * T + t
   const int ts = src_tap(kind, flip, T, t, phase);
   const float* sp = P + (size_t)ts * R * C;
-  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int n0 = bx * 32, k0 = by * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   // tile[kl][nl]
 #pragma unroll
@@ -1018,6 +1016,31 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
       *reinterpret_cast<u32x4*>(out + o) = v;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ P, unsigned short* __restrict__ out, int R,
+                                                        int C, int kind, int flip, int transpose, int T, int nphase,
+                                                        int Nn, int Npad, int Kk, int CK) {
+  __shared__ float tile[32][33];
+  pack_bf16_block(P, out, R, C, kind, flip, transpose, T, Nn, Npad, Kk, CK, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+
+// every bf16 weight copy of a network in ONE launch (after the fused Adam): item k owns the linear blocks
+// [block0, block0 + gx * gy * nphase * T), block0 ascending
+__global__ __launch_bounds__(256) void pack_bf16_batched_kernel(const s2i_pack16_item* __restrict__ items, int n) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.x;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {                       // last item with block0 <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (items[mid].block0 <= b) lo = mid;
+    else hi = mid - 1;
+  }
+  const s2i_pack16_item it = items[lo];
+  const int r = b - it.block0;
+  const int bx = r % it.gx, by = (r / it.gx) % it.gy, zt = r / (it.gx * it.gy);
+  pack_bf16_block(it.P, it.out, it.R, it.C, it.kind, it.flip, it.transpose, it.T, it.Nn, it.Npad, it.Kk, it.CK, bx, by, zt,
+                  tile);
 }
 
 // ---- split-K reduction with bf16 output (+ BatchNorm column statistics), as splitk_reduce_stats_kernel -----------------
@@ -1390,6 +1413,28 @@ extern "C" int s2i_pack_conv_weight_bf16(const s2i_conv_desc* d, const float* pa
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST, packed, out, R, C, pl.kb, d->flip, transpose, pl.T,
                      pl.nphases, Nn, pl.Npad, Kk, pl.CK);
   S2I_LAUNCH_CHECK("pack_bf16");
+  return 0;
+}
+
+extern "C" int s2i_pack16_item_fill(const s2i_conv_desc* d, const float* packed, int R, int C, unsigned short* out,
+                                    s2i_pack16_item* item) {
+  BPlan pl;
+  if (plan_bf16(d, &pl)) return -1;
+  S2I_REQUIRE(packed && out && item, "pack(bf16): null pointer");
+  const int transpose = d->wmode != 0;
+  const int Kk = d->Cx, Nn = d->N;
+  if (transpose) S2I_REQUIRE(R >= Nn && C >= Kk, "pack(bf16): P is %d x %d, need rows >= %d cols >= %d", R, C, Nn, Kk);
+  else S2I_REQUIRE(R >= Kk && C >= Nn, "pack(bf16): P is %d x %d, need rows >= %d cols >= %d", R, C, Kk, Nn);
+  item->P = packed; item->out = out; item->R = R; item->C = C; item->kind = pl.kb; item->flip = d->flip;
+  item->transpose = transpose; item->T = pl.T; item->nphase = pl.nphases; item->Nn = Nn; item->Npad = pl.Npad;
+  item->Kk = Kk; item->CK = pl.CK; item->gx = pl.Npad / 32; item->gy = Kk / 32; item->block0 = 0;
+  return item->gx * item->gy * pl.nphases * pl.T;   // blocks of this item
+}
+
+extern "C" int s2i_pack_conv_weights_bf16_batched(const s2i_pack16_item* items_dev, int n, int total_blocks, void* stream) {
+  S2I_REQUIRE(items_dev && n > 0 && total_blocks > 0, "pack(bf16, batched): empty table");
+  hipLaunchKernelGGL(pack_bf16_batched_kernel, dim3(total_blocks), dim3(256), 0, ST, items_dev, n);
+  S2I_LAUNCH_CHECK("pack_bf16_batched");
   return 0;
 }
 

@@ -182,6 +182,49 @@ def refresh_packed(params):
     for p, mode, out in entries:
         out._s2i_gen = getattr(out, '_s2i_gen', 0) + 1
         p._s2i_packs[mode] = (out, p._version, p.data_ptr())
+    _refresh_bf16([out for _, _, out in entries])
+
+
+_pack16_tables = {}
+
+
+def _refresh_bf16(packed_list):
+    """Every bf16 copy that was ever derived from these packed fp32 tensors (bf16_weight below) re-derived in ONE launch,
+    instead of one 10 us launch per layer on its first use after the optimiser step (70 launches per step at config 4)."""
+    recs = []
+    for packed in packed_list:
+        descs = getattr(packed, '_s2i_b16_desc', None)
+        if descs:
+            for key, (d, w_offset, ent) in descs.items():
+                recs.append((packed, key, d, w_offset, ent))
+    if not recs:
+        return
+    lib = _lib_ready()
+    tkey = tuple((packed.data_ptr(), key, ent.data_ptr()) for packed, key, _, _, ent in recs)
+    tab = _pack16_tables.get(tkey)
+    if tab is None:
+        items = (_lib.Pack16Item * len(recs))()
+        block0 = 0
+        for k, (packed, key, d, w_offset, ent) in enumerate(recs):
+            nb = lib.s2i_pack16_item_fill(ctypes.byref(d), ptr(packed) + 4 * int(w_offset), packed.shape[1], packed.shape[2],
+                                          ptr(ent), ctypes.byref(items[k]))
+            if nb <= 0:
+                check(1, "s2i_pack16_item_fill")
+            items[k].block0 = block0
+            block0 += nb
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(recs[0][0].device)
+        tab = (raw, len(recs), block0)
+        if len(_pack16_tables) > 64:
+            _pack16_tables.clear()
+        _pack16_tables[tkey] = tab
+    check(lib.s2i_pack_conv_weights_bf16_batched(ptr(tab[0]), tab[1], tab[2], stream()), "s2i_pack_conv_weights_bf16_batched")
+    for packed, key, d, w_offset, ent in recs:
+        gen = getattr(packed, '_s2i_gen', 0)
+        cache = getattr(packed, '_s2i_b16', None)
+        if cache is None or cache[0] != gen:
+            cache = (gen, {})
+            packed._s2i_b16 = cache
+        cache[1][key] = ent
 
 
 def pack_weight(w, mode, out=None):
@@ -279,6 +322,13 @@ def bf16_weight(packed, d, w_offset):
         check(lib.s2i_pack_conv_weight_bf16(ctypes.byref(d), ptr(packed) + 4 * int(w_offset), packed.shape[1],
                                             packed.shape[2], ptr(ent), stream()), "s2i_pack_conv_weight_bf16")
         cache[1][key] = ent
+        # remembered for the batched re-derivation after the next optimiser step (_refresh_bf16)
+        descs = getattr(packed, '_s2i_b16_desc', None)
+        if descs is None:
+            descs = packed._s2i_b16_desc = {}
+        dd = ConvDesc()
+        ctypes.memmove(ctypes.byref(dd), ctypes.byref(d), ctypes.sizeof(ConvDesc))
+        descs[key] = (dd, int(w_offset), ent)
     return ent
 
 
