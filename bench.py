@@ -91,7 +91,7 @@ def _time_launch(fn, reps=20):
 
 
 def bf16_kernel_roofline(dev, B):
-    """bf16 mode (BASELINE config 4): live HIP-event timing of the dominant kernel, conv_bf16_kernel, on its heaviest
+    """bf16 mode (BASELINE config 4): live HIP-event timing of the dominant kernel, conv_bf16_v2_kernel, on its heaviest
     launch of the step: D_NET256's Conv2d(64,128,k4,s2,p1) on the stacked (real | wrong | fake) batch, (3B,128,128,64)
     bf16 NHWC.  Algorithmic bytes per launch (SURVEY.md section 8d rule at 2 B / element): the input read once, the raw
     output written once, the bf16 weights read once."""
@@ -111,8 +111,9 @@ def bf16_kernel_roofline(dev, B):
             "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
             "frac_profiled": round(abytes / (prof["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4) if prof.get("avg_ns") else None,
             "profiled_source": prof.get("avg_source"),
-            "kernel": "conv_bf16_kernel<K4S2, BN 128, CK 32, 4 taps per stage> (v_mfma_f32_32x32x16_bf16, LDS-staged 10x66-pixel "
-                      "input patch)",
+            "kernel": "conv_bf16_v2_kernel<K4S2, CK 32, 4 taps per stage, 66-pixel padded patch rows> (v_mfma_f32_32x32x16_bf16; "
+                      "256-pixel x 128-channel tiles, LDS-staged 18x66-pixel input patch, one persistent block per CU "
+                      "prefetching its next tile)",
             "algorithmic_bytes": abytes,
             "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (ms * 1e-3) / 2.5e15, 4),
             "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) bf16 NHWC, %.1f MB algorithmic, %.2f GFLOP, %.3f ms"

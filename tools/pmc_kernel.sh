@@ -9,7 +9,7 @@ import csv, glob, collections
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(f)):
-    if any(k in r["Kernel_Name"] for k in ("conv_bf16_kernel", "igemm_fwd_kernel", "igemm_wgrad")):
+    if any(k in r["Kernel_Name"] for k in ("conv_bf16_v2_kernel", "conv_bf16_kernel", "igemm_fwd_kernel", "igemm_wgrad")):
         a = acc[(r["Kernel_Name"][:60], r["Counter_Name"])]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for (k, c), (v, n) in sorted(acc.items()):

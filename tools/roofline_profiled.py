@@ -6,7 +6,7 @@ usage: python tools/roofline_profiled.py <gpurun_out/roofline_tag> <tag>"""
 import collections, csv, glob, json, os, shutil, sys
 
 out, tag = sys.argv[1], sys.argv[2]
-KEY = ("conv_bf16_kernel", "igemm_fwd_kernel", "igemm_fwd_split_kernel")
+KEY = ("conv_bf16_v2_kernel", "conv_bf16_kernel", "igemm_fwd_kernel", "igemm_fwd_split_kernel")
 
 
 def dominant(rows, name_col):
