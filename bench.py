@@ -363,6 +363,7 @@ def main():
     exec_log, ops.EXEC_LOG = ops.EXEC_LOG, None
     tr._graph = graph_state
     exec_flops = sum(r[1] for r in exec_log)
+    step_peak_tf = 2500.0 if args.math in ("bf16", "bf16p") else PEAK_F32_TFLOPS
 
     if rank == 0:
         note("timed region done: %.3f s for %d steps" % (elapsed, args.steps))
@@ -389,15 +390,17 @@ def main():
                        "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math],
                        "hip_graph": bool(tr._graph is not None and tr._graph.get("graph") is not None)},
             "step_roofline": {
+                # fractions against the dense MFMA peak of the arithmetic the mode computes in (fp32 157.3; bf16 2500)
                 # what the matrix cores really deliver: multiply-adds of the launched GEMMs (up-blocks at 4 taps per
                 # output parity, c_code folded into a class bias, no D weight gradients in the G update)
                 "executed_tflops": round(exec_flops / (ms * 1e-3) / 1e12, 2),
-                "executed_flops_frac": round(exec_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
+                "executed_flops_frac": round(exec_flops / (ms * 1e-3) / (step_peak_tf * 1e12), 4),
+                "flops_peak_tflops": step_peak_tf,
                 "executed_gflop_per_image": round(exec_flops / B / 1e9, 2),
                 "matrix_launches_per_step": len(exec_log),
                 # the reference's own FLOP count for the same step: what a literal execution would need
                 "algorithmic_equiv_tflops": round(step_flops / (ms * 1e-3) / 1e12, 2),
-                "algorithmic_equiv_frac": round(step_flops / (ms * 1e-3) / (PEAK_F32_TFLOPS * 1e12), 4),
+                "algorithmic_equiv_frac": round(step_flops / (ms * 1e-3) / (step_peak_tf * 1e12), 4),
                 "hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                 "algorithmic_gbytes_per_step": round(step_bytes / 1e9, 2),
                 "note": "executed_* = 2*M*N*K over the launched GEMM descriptors of one step; algorithmic_equiv_* credits "
