@@ -2058,6 +2058,31 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
     if (splitk > 64) splitk = 64;
     if (splitk < 1) splitk = 1;
   }
+  // Round quantisation (round 2; profiles/r02_f32_per_launch_table.txt): launches whose blocks fill whole rounds of the
+  // chip's 768 slots run at 121 - 125 TFLOP/s, 576 or 1152 blocks (0.75 / 1.5 rounds) at 100.  Where K is long, split it so
+  // that blocks x splitk comes close to whole rounds -- if the fp32 slabs (splitk writes + reads of the output at ~4 TB/s)
+  // cost less than the idle slots.  Measured: the launches in question alone go from 98 - 100 to 116 - 120 TFLOP/s (0.6 ms of
+  // the 28.2 ms of matrix launches per step), but the STEP gets slower (32.37 vs 32.17 ms): in the step the idle slots of
+  // one discriminator's launch are filled by the other discriminators' streams, and the split adds slab traffic and a
+  // reduction launch.  Opt-in: S2I_SPLIT_ROUNDS=1.
+  static const bool rounds_on = getenv("S2I_SPLIT_ROUNDS") && atoi(getenv("S2I_SPLIT_ROUNDS")) != 0;
+  if (rounds_on && !d->nosplit && pl->nchunks >= 32 && blocks * splitk >= 256 && d->kind != S2I_CONV_1D) {
+    const int BNt = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
+    // seconds of one full round of unsplit blocks at the measured full-round rate, and of the slab traffic of a split
+    const double t_round = 768.0 * 2.0 * 128.0 * BNt * pl->K / 123e12;
+    const double slab_unit = (double)pl->Mrows * d->N * 4.0 * 2.0 / 4.0e12;   // one slab written + read
+    double best = 1e30;
+    int best_s = splitk;
+    const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    for (int s : cand) {
+      if (s < splitk || s > pl->nchunks / 8) continue;
+      const int cps = s2i_cdiv(pl->nchunks, s), se = s2i_cdiv(pl->nchunks, cps);   // effective split
+      const double rounds = (double)((blocks * se + 767) / 768);
+      const double t = rounds * t_round / se + (se > 1 ? se * slab_unit + 8e-6 : 0.0);
+      if (t < best * 0.97) { best = t; best_s = se; }
+    }
+    splitk = best_s;
+  }
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
   return 0;
