@@ -174,8 +174,22 @@ BLOCK_CASES = [
 ]
 
 
+@pytest.mark.parametrize("case", [BLOCK_CASES[0], BLOCK_CASES[1], BLOCK_CASES[4]],
+                         ids=lambda c: "-".join(str(v) for v in c))
+def test_bf16_fused_block_second_generation_kernels(gpu, case, bf16_mode, monkeypatch):
+    """The fused block (class-bias epilogue, BatchNorm sums per tile, both gradients) through conv_bf16_v2_kernel: the three
+    block cases with more than 64 output channels."""
+    monkeypatch.setenv("S2I_B16_V2", "2")
+    monkeypatch.setenv("S2I_B16_PERSISTENT", "4")
+    _block_case(gpu, case)
+
+
 @pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: "-".join(str(v) for v in c))
 def test_bf16_fused_block_tracks_fp32_reference(gpu, case, bf16_mode):
+    _block_case(gpu, case)
+
+
+def _block_case(gpu, case):
     """conv + BatchNorm + GLU / LeakyReLU / residual with bf16 storage, forward and backward, against torch fp32 on the
     same (bf16-rounded) inputs.  Relative L2 deviation is printed and bounded by 1.5e-2 (outputs) / 1e-2 (gradients; 6e-2
     behind a LeakyReLU, see below)."""
