@@ -327,6 +327,12 @@ class _DNet(nn.Module):
         `taps` (a list, tests only) receives the NHWC output of every LeakyReLU block in forward order."""
         x = ops.ToNHWC.apply(x_var, 4)
         x_code = self.img_code_s16(x, groups, taps)
+        hook = getattr(self, 'after_s16_hook', None)
+        if hook is not None and x_code.requires_grad:
+            # fires when the gradient of img_code_s16's output exists, i.e. when the parameter gradients of the tower and
+            # the heads (96 % of D_NET256's parameters) have been issued: the data-parallel trainer starts reducing that
+            # part of the flat gradient there, under the backward of the four image-side convolutions
+            x_code.register_hook(hook)
         for name in self._tower:
             x_code = getattr(self, name)(x_code, groups=groups)
             if taps is not None:

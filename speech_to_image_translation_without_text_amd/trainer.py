@@ -287,6 +287,7 @@ class condGANTrainer(object):
                     torch.distributed.broadcast(buf, 0)
             self.rank = torch.distributed.get_rank()
             self._install_g_overlap()
+            self._install_d_overlap()
         self.avg_param_G = self.flatG.avg_params()
         return start_count
 
@@ -338,6 +339,39 @@ class condGANTrainer(object):
         h1.after_up1_hook = hook
         self._g_hook_armed = False
 
+    def _install_d_overlap(self):
+        """The same for the discriminators: the parameters behind img_code_s16 in parameter order (tower, jointConv, logit
+        heads: 68 of D_NET256's 71 M parameters) have their gradients first in the backward; their all-reduce starts from a
+        hook on img_code_s16's output and runs under the backward of the four image-side convolutions, which is most of a
+        discriminator's backward time.  Same sums as one all-reduce (`S2I_D_OVERLAP=0`: one all-reduce after the backward)."""
+        n = len(self.netsD)
+        self._d_split, self._d_tail_work = [None] * n, [None] * n
+        self._d_hook_armed, self._d_fires, self._d_expected = [False] * n, [0] * n, [1] * n
+        if os.environ.get("S2I_D_OVERLAP", "1") != "1":
+            return
+        for idx, netD in enumerate(self.netsD):
+            d = _unwrap(netD)
+            flat = self.flatsD[idx]
+            head = {id(p) for p in d.img_code_s16.parameters()}
+            k = 0
+            while k < len(flat.params) and id(flat.params[k]) in head:
+                k += 1
+            if k == 0 or k >= len(flat.params):
+                continue
+            split = flat.offsets[k]
+            if flat.g.numel() - split < int(os.environ.get("S2I_D_OVERLAP_MIN", str(1 << 20))):
+                continue                                   # a tail below 4 MB is not worth a second collective
+            self._d_split[idx] = split
+
+            def hook(grad, idx=idx):
+                if self._d_hook_armed[idx]:
+                    self._d_fires[idx] += 1
+                    if self._d_fires[idx] == self._d_expected[idx]:   # un-stacked passes: the last of the three
+                        self._d_hook_armed[idx] = False
+                        self._d_tail_work[idx] = self._reduce_async(self.flatsD[idx], self._d_split[idx], None)
+                return None
+            d.after_s16_hook = hook
+
     # -- D update (trainer.py:375-427) ----------------------------------------------------------------------------
     def _d_logits(self, idx):
         """Conditional/unconditional probabilities of the real, wrong and fake batches.  When the batch is a
@@ -346,7 +380,10 @@ class condGANTrainer(object):
         netD = self.netsD[idx]
         mu = self.mu.detach()
         B = mu.shape[0]
-        if self.stack_d_passes and B % 8 == 0:
+        stacked = self.stack_d_passes and B % 8 == 0
+        if getattr(self, '_d_expected', None) is not None:
+            self._d_expected[idx] = 1 if stacked else 3     # backward firings of the img_code_s16 hook
+        if stacked:
             x = torch.cat((self.real_imgs[idx], self.wrong_imgs[idx], self.fake_imgs[idx].detach()), 0)
             logits, _ = _unwrap(netD)(x, mu.repeat(3, 1), groups=3, need_features=False)
             self._stacked_logits = logits
@@ -380,21 +417,33 @@ class condGANTrainer(object):
     def train_Dnet(self, idx, count, defer_step=False):
         flat = self.flatsD[idx]
         flat.zero_grad()
+        split = getattr(self, '_d_split', [None] * self.num_Ds)[idx] if self.distributed else None
+        if split is not None:
+            self._d_tail_work[idx], self._d_fires[idx] = None, 0
+            self._d_hook_armed[idx] = True
         errD = self._d_loss(idx)
         errD.backward()
-        work = self._reduce_async(flat)
-        if defer_step:
-            self._pending.append((flat, work))
+        if split is not None:
+            self._d_hook_armed[idx] = False
+        if split is not None and self._d_tail_work[idx] is not None:
+            works = [self._reduce_async(flat, 0, split), self._d_tail_work[idx]]   # head chunk: img_code_s16
+            self._d_tail_work[idx] = None
         else:
-            if work is not None:
-                work.wait()
+            works = [self._reduce_async(flat)]
+        if defer_step:
+            self._pending.append((flat, works))
+        else:
+            for work in works:
+                if work is not None:
+                    work.wait()
             flat.adam(1.0 / self.world)
         return errD
 
     def _flush_d_steps(self):
-        for flat, work in self._pending:
-            if work is not None:
-                work.wait()
+        for flat, works in self._pending:
+            for work in works:
+                if work is not None:
+                    work.wait()
             flat.adam(1.0 / self.world)
         self._pending = []
 

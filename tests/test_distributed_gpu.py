@@ -20,6 +20,7 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ["S2I_D_OVERLAP_MIN"] = "0"      # the reduced-width discriminators are small: split their all-reduce anyway
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import CASES, build_nets, make_batch
@@ -35,6 +36,9 @@ def _worker(rank, world, port, out_dir):
             d.to(dev)
         tr = T.condGANTrainer(None, None, 256, False, local_rank=0, distributed=True)
         tr.build(netG, netsD)
+        # D_NET128 / D_NET256 reduce in two chunks (tower + heads from a backward hook, then img_code_s16); at this batch
+        # (not a multiple of 8) the three passes are separate calls, so the hook must wait for its third firing
+        assert tr._d_split[1] is not None and tr._d_split[2] is not None
         batch = make_batch(case)
         b = {k: ([t.to(dev) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else
                  (v.to(dev) if torch.is_tensor(v) else v)) for k, v in batch.items()}
@@ -73,6 +77,7 @@ def _rccl_worker(rank, world, port, out_dir):
     bit-identical to the non-distributed step."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["S2I_D_OVERLAP_MIN"] = "0"
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dev = torch.device("cuda:0")
@@ -95,6 +100,7 @@ def _rccl_worker(rank, world, port, out_dir):
             tr.build(netG, netsD)
             if distributed:
                 assert tr._g_split is not None and 0 < tr._g_split < tr.flatG.total
+                assert tr._d_split[2] is not None and 0 < tr._d_split[2] < tr.flatsD[2].total
             for it in range(2):
                 out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'],
                                     b['noise'], b['eps'])
