@@ -11,7 +11,7 @@ from speech_to_image_translation_without_text_amd.miscc.config import cfg, cfg_f
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 ops.MATH_PLANES = int(os.environ.get("S2I_MATH_PLANES", "0"))
-B = 24
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 24      # usage: soak.py [steps] [batch]; S2I_ACT_BF16=1 for the bf16 mode
 dev = torch.device("cuda:0")
 cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
 cfg.TRAIN.BATCH_SIZE = B
