@@ -8,6 +8,16 @@
 namespace {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + __expf(-v)); }
+// the gate of the GLU passes over bf16 tensors: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x2,
+// v_rcp, four v_fma, v_div_fmas, v_div_fixup): those passes are VALU-bound (tools/elementwise_bench.py: GLU backward
+// reduce 1.75 -> 2.64 TB/s), and the gate's relative error stays ~1e-7, far below the bf16 rounding of its operands.
+// fp32 tensors, the logit heads and the LSTM keep the exact form (the fp32 parity tests sit on LeakyReLU decisions that a
+// 1e-7 perturbation re-rolls).
+struct bf16_t;
+template <typename T> __device__ __forceinline__ float sigmoid_gate_(float v) {
+  if constexpr (sizeof(T) == 2) return __builtin_amdgcn_rcpf(1.f + __expf(-v));
+  else return 1.f / (1.f + __expf(-v));
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -69,7 +79,7 @@ __device__ __forceinline__ f32x4 act_dz(const T* __restrict__ y, const T* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float za = sa[j] * ya[j] + ta[j];
-      const float sgm = sigmoidf_(sg[j] * yg[j] + tg[j]);
+      const float sgm = sigmoid_gate_<T>(sg[j] * yg[j] + tg[j]);
       dz[j] = first ? d[j] * sgm : d[j] * za * sgm * (1.f - sgm);
     }
   } else {
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
       const f32x4 sa = ld4(scale + q * 4), ta = ld4(shift + q * 4);
       const f32x4 sg = ld4(scale + Cout + q * 4), tg = ld4(shift + Cout + q * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (sa[j] * ya[j] + ta[j]) * sigmoidf_(sg[j] * yg[j] + tg[j]);
+      for (int j = 0; j < 4; ++j) o[j] = (sa[j] * ya[j] + ta[j]) * sigmoid_gate_<T>(sg[j] * yg[j] + tg[j]);
     } else {
       const f32x4 yv = ld4(y + row * C + q * 4);
       const f32x4 sc = ld4(scale + q * 4), sh = ld4(shift + q * 4);
@@ -1085,6 +1095,338 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long
     st4(dst + e * 4, ld4(src + e * 4));
 }
 
+// ---- row-tiled BatchNorm / activation passes (round 2) --------------------------------------------------------------------
+// The grid-stride forms above walk (row, channel quad) pairs: one 64-bit division, up to six coefficient loads and ONE
+// 8- or 16-byte activation load in flight per thread and iteration.  Measured (tools/elementwise_bench.py, config 4 shapes):
+// bf16 tensors moved at the same ROWS per second as fp32 ones, i.e. at half the bytes per second (1.8 - 3.6 TB/s in the
+// backward passes), and the GLU forms at half of that again (both halves' threads load both halves and both compute the
+// sigmoid).  These kernels fix a thread to V channels (8 for bf16: 16-byte loads; 4 for fp32) and let it walk rows: every
+// coefficient lives in registers, there is no division, two rows' loads are issued before the first is used, and a GLU pair
+// (value channel c, gate channel C/2 + c) is ONE thread's work.
+#define S2I_EW_ROWS_DEFAULT 1   // measured: the forward form wins for bf16 tensors; the backward forms lose to the walkers above
+typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+template <int V> struct fv { f32x4 v[V / 4]; };
+
+template <int V> __device__ __forceinline__ fv<V> ldv(const float* p) {
+  fv<V> r;
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k) r.v[k] = *reinterpret_cast<const f32x4*>(p + 4 * k);
+  return r;
+}
+template <int V> __device__ __forceinline__ fv<V> ldv(const bf16_t* p) {
+  fv<V> r;
+  if constexpr (V == 4) {
+    r.v[0] = ld4(p);
+  } else {
+    const u32x4e h = *reinterpret_cast<const u32x4e*>(p);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      r.v[k] = f32x4{__builtin_bit_cast(float, h[2 * k] << 16), __builtin_bit_cast(float, h[2 * k] & 0xffff0000u),
+                     __builtin_bit_cast(float, h[2 * k + 1] << 16), __builtin_bit_cast(float, h[2 * k + 1] & 0xffff0000u)};
+  }
+  return r;
+}
+template <int V> __device__ __forceinline__ void stv(float* p, const fv<V>& a) {
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k) *reinterpret_cast<f32x4*>(p + 4 * k) = a.v[k];
+}
+template <int V> __device__ __forceinline__ void stv(bf16_t* p, const fv<V>& a) {
+  if constexpr (V == 4) {
+    st4(p, a.v[0]);
+  } else {
+    u32x4e h;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const f32x2_ lo = {a.v[k][0], a.v[k][1]}, hi = {a.v[k][2], a.v[k][3]};
+      h[2 * k] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2_));
+      h[2 * k + 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2_));
+    }
+    *reinterpret_cast<u32x4e*>(p) = h;
+  }
+}
+
+// rows of this block: the rows are `G` independent BatchNorm batches of Rg rows, each walked by ppg blocks
+struct RowSpan { long long r0, r1; int grp; };
+__device__ __forceinline__ RowSpan row_span(long long M, int ppg, long long Rg) {
+  RowSpan s;
+  s.grp = blockIdx.x / ppg;
+  const int pp = blockIdx.x - s.grp * ppg;
+  const long long chunk = (Rg + ppg - 1) / ppg;
+  s.r0 = s.grp * Rg + pp * chunk;
+  const long long gend = (s.grp + 1) * Rg < M ? (s.grp + 1) * Rg : M;
+  s.r1 = s.r0 + chunk < gend ? s.r0 + chunk : gend;
+  return s;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const T* __restrict__ y, long long M, int C,
+                                                              const float* __restrict__ coef0, int act,
+                                                              const T* __restrict__ residual, T* __restrict__ out,
+                                                              int lgc, int ppg, long long Rg) {
+  const int cpb = 1 << lgc, rpb = 256 >> lgc;
+  const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
+  const bool glu = act == S2I_ACT_GLU;
+  const int Cout = glu ? C / 2 : C;
+  const int c0 = (blockIdx.y * cpb + ql) * V;
+  if (c0 >= Cout) return;
+  const RowSpan sp = row_span(M, ppg, Rg);
+  const float* scale = coef0 + (size_t)sp.grp * 4 * C + 2 * C;
+  const float* shift = scale + C;
+  const fv<V> sa = ldv<V>(scale + c0), ta = ldv<V>(shift + c0);
+  fv<V> sg, tg;
+  if (glu) { sg = ldv<V>(scale + Cout + c0); tg = ldv<V>(shift + Cout + c0); }
+  auto one = [&](long long row, const fv<V>& ya, const fv<V>& yx) {   // yx: gate half (GLU) or residual
+    fv<V> o;
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = sa.v[k][j] * ya.v[k][j] + ta.v[k][j];
+        if (glu) z *= sigmoid_gate_<T>(sg.v[k][j] * yx.v[k][j] + tg.v[k][j]);
+        else if (act == S2I_ACT_LRELU) z = z > 0.f ? z : 0.2f * z;
+        if (!glu && residual) z += yx.v[k][j];
+        o.v[k][j] = z;
+      }
+    stv<V>(out + row * Cout + c0, o);
+  };
+  const bool two = glu || residual != nullptr;
+  const T* second = glu ? y + Cout : residual;
+  const long long ld2 = glu ? C : Cout;
+  long long row = sp.r0 + rl;
+  for (; row + rpb < sp.r1; row += 2 * rpb) {
+    const fv<V> a0 = ldv<V>(y + row * C + c0), a1 = ldv<V>(y + (row + rpb) * C + c0);
+    fv<V> x0 = a0, x1 = a1;
+    if (two) { x0 = ldv<V>(second + row * ld2 + c0); x1 = ldv<V>(second + (row + rpb) * ld2 + c0); }
+    one(row, a0, x0);
+    one(row + rpb, a1, x1);
+  }
+  if (row < sp.r1) {
+    const fv<V> a0 = ldv<V>(y + row * C + c0);
+    fv<V> x0 = a0;
+    if (two) x0 = ldv<V>(second + row * ld2 + c0);
+    one(row, a0, x0);
+  }
+}
+
+// per-half coefficient registers of the backward passes
+template <int V> struct BnCo { fv<V> s, t, mean, istd; };
+template <int V> __device__ __forceinline__ BnCo<V> bn_co(const float* coef, int C, int c0) {
+  BnCo<V> c;
+  c.mean = ldv<V>(coef + c0); c.istd = ldv<V>(coef + C + c0); c.s = ldv<V>(coef + 2 * C + c0); c.t = ldv<V>(coef + 3 * C + c0);
+  return c;
+}
+
+// dz of one row for this thread's channels.  GLU: (value half a, gate half g) -> (dz_a, dz_g); otherwise dz_a only.
+template <typename T, int V>
+__device__ __forceinline__ void row_dz(int act, const BnCo<V>& ca, const BnCo<V>& cg, const fv<V>& ya, const fv<V>& yg,
+                                       const fv<V>& d, fv<V>& dza, fv<V>& dzg) {
+#pragma unroll
+  for (int k = 0; k < V / 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float za = ca.s.v[k][j] * ya.v[k][j] + ca.t.v[k][j];
+      if (act == S2I_ACT_GLU) {
+        const float sgm = sigmoid_gate_<T>(cg.s.v[k][j] * yg.v[k][j] + cg.t.v[k][j]);
+        dza.v[k][j] = d.v[k][j] * sgm;
+        dzg.v[k][j] = d.v[k][j] * za * sgm * (1.f - sgm);
+      } else if (act == S2I_ACT_LRELU) {
+        dza.v[k][j] = za > 0.f ? d.v[k][j] : 0.2f * d.v[k][j];
+      } else {
+        dza.v[k][j] = d.v[k][j];
+      }
+    }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
+                                                                    int lddout, long long M, int C,
+                                                                    const float* __restrict__ coef0,
+                                                                    const float* __restrict__ red20, int act,
+                                                                    T* __restrict__ dy, int lgc, int ppg, long long Rg) {
+  const int cpb = 1 << lgc, rpb = 256 >> lgc;
+  const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
+  const bool glu = act == S2I_ACT_GLU;
+  const int Ch = glu ? C / 2 : C;                       // channels the threads are spread over
+  const int c0 = (blockIdx.y * cpb + ql) * V;
+  if (c0 >= Ch) return;
+  const RowSpan sp = row_span(M, ppg, Rg);
+  const float* coef = coef0 + (size_t)sp.grp * 4 * C;
+  const float* red2 = red20 + (size_t)sp.grp * 2 * C;
+  const BnCo<V> ca = bn_co<V>(coef, C, c0);
+  BnCo<V> cg = ca;
+  const fv<V> m0a = ldv<V>(red2 + c0), m1a = ldv<V>(red2 + C + c0);
+  fv<V> m0g = m0a, m1g = m1a;
+  if (glu) { cg = bn_co<V>(coef, C, Ch + c0); m0g = ldv<V>(red2 + Ch + c0); m1g = ldv<V>(red2 + C + Ch + c0); }
+  auto one = [&](long long row, const fv<V>& ya, const fv<V>& yg, const fv<V>& d) {
+    fv<V> dza, dzg, oa, og;
+    row_dz<T, V>(act, ca, cg, ya, yg, d, dza, dzg);
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xa = (ya.v[k][j] - ca.mean.v[k][j]) * ca.istd.v[k][j];
+        oa.v[k][j] = ca.s.v[k][j] * (dza.v[k][j] - m0a.v[k][j] - xa * m1a.v[k][j]);
+        if (glu) {
+          const float xg = (yg.v[k][j] - cg.mean.v[k][j]) * cg.istd.v[k][j];
+          og.v[k][j] = cg.s.v[k][j] * (dzg.v[k][j] - m0g.v[k][j] - xg * m1g.v[k][j]);
+        }
+      }
+    stv<V>(dy + row * C + c0, oa);
+    if (glu) stv<V>(dy + row * C + Ch + c0, og);
+  };
+  long long row = sp.r0 + rl;
+  for (; row + rpb < sp.r1; row += 2 * rpb) {
+    const fv<V> a0 = ldv<V>(y + row * C + c0), a1 = ldv<V>(y + (row + rpb) * C + c0);
+    const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
+    fv<V> g0 = a0, g1 = a1;
+    if (glu) { g0 = ldv<V>(y + row * C + Ch + c0); g1 = ldv<V>(y + (row + rpb) * C + Ch + c0); }
+    one(row, a0, g0, d0);
+    one(row + rpb, a1, g1, d1);
+  }
+  if (row < sp.r1) {
+    const fv<V> a0 = ldv<V>(y + row * C + c0), d0 = ldv<V>(dout + row * lddout + c0);
+    fv<V> g0 = a0;
+    if (glu) g0 = ldv<V>(y + row * C + Ch + c0);
+    one(row, a0, g0, d0);
+  }
+}
+
+// column sums of (dz, dz * xhat) over this block's rows: part[0 / 1][blockIdx.x][C], as colreduce_kernel<1>
+template <typename T, int V>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
+                                                                     int lddout, long long M, int C,
+                                                                     const float* __restrict__ coef0, int act,
+                                                                     float* __restrict__ part, int nparts, int lgc, int ppg,
+                                                                     long long Rg) {
+  constexpr int NQ = V / 4;
+  __shared__ f32x4 sh[4 * NQ][256];                     // [sum index][thread]
+  const int cpb = 1 << lgc, rpb = 256 >> lgc;
+  const int tid = threadIdx.x, ql = tid & (cpb - 1), rl = tid >> lgc;
+  const bool glu = act == S2I_ACT_GLU;
+  const int Ch = glu ? C / 2 : C;
+  const int c0 = (blockIdx.y * cpb + ql) * V;
+  const bool live = c0 < Ch;
+  const RowSpan sp = row_span(M, ppg, Rg);
+  fv<V> s0a, s1a, s0g, s1g;
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) s0a.v[k] = s1a.v[k] = s0g.v[k] = s1g.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const float* coef = coef0 + (size_t)sp.grp * 4 * C;
+    const BnCo<V> ca = bn_co<V>(coef, C, c0);
+    BnCo<V> cg = ca;
+    if (glu) cg = bn_co<V>(coef, C, Ch + c0);
+    auto one = [&](const fv<V>& ya, const fv<V>& yg, const fv<V>& d) {
+      fv<V> dza, dzg;
+      row_dz<T, V>(act, ca, cg, ya, yg, d, dza, dzg);
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        s0a.v[k] += dza.v[k];
+        s1a.v[k] += dza.v[k] * ((ya.v[k] - ca.mean.v[k]) * ca.istd.v[k]);
+        if (glu) {
+          s0g.v[k] += dzg.v[k];
+          s1g.v[k] += dzg.v[k] * ((yg.v[k] - cg.mean.v[k]) * cg.istd.v[k]);
+        }
+      }
+    };
+    long long row = sp.r0 + rl;
+    for (; row + rpb < sp.r1; row += 2 * rpb) {
+      const fv<V> a0 = ldv<V>(y + row * C + c0), a1 = ldv<V>(y + (row + rpb) * C + c0);
+      const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
+      fv<V> g0 = a0, g1 = a1;
+      if (glu) { g0 = ldv<V>(y + row * C + Ch + c0); g1 = ldv<V>(y + (row + rpb) * C + Ch + c0); }
+      one(a0, g0, d0);
+      one(a1, g1, d1);
+    }
+    if (row < sp.r1) {
+      const fv<V> a0 = ldv<V>(y + row * C + c0), d0 = ldv<V>(dout + row * lddout + c0);
+      fv<V> g0 = a0;
+      if (glu) g0 = ldv<V>(y + row * C + Ch + c0);
+      one(a0, g0, d0);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    sh[0 * NQ + k][tid] = s0a.v[k];
+    sh[1 * NQ + k][tid] = s1a.v[k];
+    sh[2 * NQ + k][tid] = s0g.v[k];
+    sh[3 * NQ + k][tid] = s1g.v[k];
+  }
+  __syncthreads();
+  if (rl == 0 && live) {
+    for (int r = 1; r < rpb; ++r)
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        s0a.v[k] += sh[0 * NQ + k][r * cpb + ql];
+        s1a.v[k] += sh[1 * NQ + k][r * cpb + ql];
+        if (glu) {
+          s0g.v[k] += sh[2 * NQ + k][r * cpb + ql];
+          s1g.v[k] += sh[3 * NQ + k][r * cpb + ql];
+        }
+      }
+    float* p0 = part + ((size_t)0 * nparts + blockIdx.x) * C;
+    float* p1 = part + ((size_t)1 * nparts + blockIdx.x) * C;
+    stv<V>(p0 + c0, s0a);
+    stv<V>(p1 + c0, s1a);
+    if (glu) { stv<V>(p0 + Ch + c0, s0g); stv<V>(p1 + Ch + c0, s1g); }
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void act_bwd_rows_kernel(const T* __restrict__ out, const T* __restrict__ dout,
+                                                           int lddout, long long M, int C, int act, T* __restrict__ dy,
+                                                           int lgc, int ppg) {
+  const int cpb = 1 << lgc, rpb = 256 >> lgc;
+  const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
+  const int c0 = (blockIdx.y * cpb + ql) * V;
+  if (c0 >= C) return;
+  const RowSpan sp = row_span(M, ppg, M);
+  auto one = [&](long long row, const fv<V>& ov, const fv<V>& d) {
+    fv<V> o;
+#pragma unroll
+    for (int k = 0; k < V / 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (act == S2I_ACT_LRELU) o.v[k][j] = ov.v[k][j] > 0.f ? d.v[k][j] : 0.2f * d.v[k][j];
+        else if (act == S2I_ACT_TANH) o.v[k][j] = d.v[k][j] * (1.f - ov.v[k][j] * ov.v[k][j]);
+        else o.v[k][j] = d.v[k][j];
+      }
+    stv<V>(dy + row * C + c0, o);
+  };
+  long long row = sp.r0 + rl;
+  for (; row + rpb < sp.r1; row += 2 * rpb) {
+    const fv<V> o0 = ldv<V>(out + row * C + c0), o1 = ldv<V>(out + (row + rpb) * C + c0);
+    const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
+    one(row, o0, d0);
+    one(row + rpb, o1, d1);
+  }
+  if (row < sp.r1) one(row, ldv<V>(out + row * C + c0), ldv<V>(dout + row * lddout + c0));
+}
+
+// S2I_EW_ROWS: which passes take the row-tiled kernels (bit 0 forward, 1 backward reduce, 2 backward apply, 3 plain
+// activation backward); read per call (tools/elementwise_bench.py switches it)
+static int ew_rows_mask() {
+  const char* e = getenv("S2I_EW_ROWS");
+  return e ? atoi(e) : S2I_EW_ROWS_DEFAULT;
+}
+
+// host geometry of the row-tiled kernels: threads across the channel vectors (a power of two), the rest of the block
+// down the rows; enough blocks along the rows to keep ~16 waves per CU busy with at least a few trips each
+struct RowGeom { int lgc, gy, ppg; };
+static RowGeom row_geom(int nvec, long long Rg, int groups, int want_parts) {
+  RowGeom g;
+  g.lgc = 0;
+  while ((1 << g.lgc) < nvec && g.lgc < 8) ++g.lgc;
+  const int cpb = 1 << g.lgc, rpb = 256 / cpb;
+  g.gy = (nvec + cpb - 1) / cpb;
+  if (want_parts > 0) { g.ppg = want_parts; return g; }
+  long long ppg = (Rg + (long long)rpb * 8 - 1) / ((long long)rpb * 8);   // >= 8 rows per thread where the tensor allows
+  const long long cap = 4096 / ((long long)groups * g.gy) > 0 ? 4096 / ((long long)groups * g.gy) : 1;
+  if (ppg > cap) ppg = cap;
+  if (ppg < 1) ppg = 1;
+  g.ppg = (int)ppg;
+  return g;
+}
+
 inline int grid_for(long long total, int block = 256, int cap = 2048 * 4) {
   long long g = (total + block - 1) / block;
   if (g > cap) g = cap;
@@ -1176,7 +1518,23 @@ static int bn_act_forward_impl(const T* y, long long M, int groups, int C, const
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_forward: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_forward: C=%d not aligned for act %d", C, act);
   S2I_REQUIRE(!(residual && act == S2I_ACT_GLU), "bn_act_forward: residual with GLU unsupported");
-  const long long total = M * ((act == S2I_ACT_GLU ? C / 2 : C) / 4);
+  const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
+  constexpr bool is16 = sizeof(T) == 2;
+  const bool rows_on = (ew_rows_mask() & 1) != 0 && (is16 || (ew_rows_mask() & 16) != 0);   // fp32: no gain (bit 4 forces it)
+  if (rows_on) {
+    if (is16 && (Cout % 8) == 0) {
+      const RowGeom g = row_geom(Cout / 8, M / groups, groups, 0);
+      hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, 8>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, M, C, coef4, act,
+                         residual, out, g.lgc, g.ppg, M / groups);
+    } else {
+      const RowGeom g = row_geom(Cout / 4, M / groups, groups, 0);
+      hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, 4>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, M, C, coef4, act,
+                         residual, out, g.lgc, g.ppg, M / groups);
+    }
+    S2I_LAUNCH_CHECK("bn_act_forward(rows)");
+    return 0;
+  }
+  const long long total = M * (Cout / 4);
   hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out,
                      groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_forward");
@@ -1201,6 +1559,21 @@ static int bn_act_bwd_reduce_impl(const T* y, const T* dout, int lddout, long lo
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && nparts % groups == 0, "bn_act_bwd_reduce: bad grouping");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_reduce: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_reduce: lddout alignment");
+  const bool rows_on = (ew_rows_mask() & 2) != 0;
+  if (rows_on) {
+    const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
+    if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
+      const RowGeom g = row_geom(Ch / 8, M / groups, groups, nparts / groups);
+      hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, 8>), dim3(nparts, g.gy), dim3(256), 0, ST, y, dout, lddout, M, C,
+                         coef4, act, part, nparts, g.lgc, g.ppg, M / groups);
+    } else {
+      const RowGeom g = row_geom(Ch / 4, M / groups, groups, nparts / groups);
+      hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, 4>), dim3(nparts, g.gy), dim3(256), 0, ST, y, dout, lddout, M, C,
+                         coef4, act, part, nparts, g.lgc, g.ppg, M / groups);
+    }
+    S2I_LAUNCH_CHECK("bn_act_bwd_reduce(rows)");
+    return 0;
+  }
   RedGeom g = red_geom(C);
   hipLaunchKernelGGL((colreduce_kernel<1, T>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
                      act, part, nparts, g.cpb, nparts / groups, M / groups);
@@ -1232,6 +1605,21 @@ static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long lon
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_bwd_apply: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_apply: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_apply: lddout alignment");
+  const bool rows_on = (ew_rows_mask() & 4) != 0;
+  if (rows_on) {
+    const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
+    if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
+      const RowGeom g = row_geom(Ch / 8, M / groups, groups, 0);
+      hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, 8>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, dout, lddout,
+                         M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups);
+    } else {
+      const RowGeom g = row_geom(Ch / 4, M / groups, groups, 0);
+      hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, 4>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, dout, lddout,
+                         M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups);
+    }
+    S2I_LAUNCH_CHECK("bn_act_bwd_apply(rows)");
+    return 0;
+  }
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
                      coef4, red2, act, dy, groups, (unsigned)(M / groups));
   S2I_LAUNCH_CHECK("bn_act_bwd_apply");
@@ -1252,6 +1640,20 @@ extern "C" int s2i_bn_act_bwd_apply_dt(int dtype, const void* y, const void* dou
 template <typename T>
 static int act_backward_impl(const T* out, const T* dout, int lddout, long long M, int C, int act, T* dy, void* stream) {
   S2I_REQUIRE(out && dout && dy && M > 0 && C > 0 && C % 4 == 0 && lddout % 4 == 0, "act_backward: bad args");
+  const bool rows_on = (ew_rows_mask() & 8) != 0;
+  if (rows_on) {
+    if (sizeof(T) == 2 && (C % 8) == 0 && (lddout % 8) == 0) {
+      const RowGeom g = row_geom(C / 8, M, 1, 0);
+      hipLaunchKernelGGL((act_bwd_rows_kernel<T, 8>), dim3(g.ppg, g.gy), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy,
+                         g.lgc, g.ppg);
+    } else {
+      const RowGeom g = row_geom(C / 4, M, 1, 0);
+      hipLaunchKernelGGL((act_bwd_rows_kernel<T, 4>), dim3(g.ppg, g.gy), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy,
+                         g.lgc, g.ppg);
+    }
+    S2I_LAUNCH_CHECK("act_backward(rows)");
+    return 0;
+  }
   hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
   S2I_LAUNCH_CHECK("act_backward");
   return 0;
