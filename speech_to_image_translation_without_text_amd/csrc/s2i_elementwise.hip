@@ -95,12 +95,15 @@ __device__ __forceinline__ f32x4 act_dz(const T* __restrict__ y, const T* __rest
   return dz;
 }
 
-template <int MODE, typename T>  // 0: (y, y^2)   1: (dz, dz*xhat)
+// ACT >= 0: the activation as a compile-time constant (the runtime form compiles every activation's path into one kernel:
+// 127 registers = 4 waves per SIMD; specialised, the LeakyReLU form needs far fewer), RPT rows per trip
+template <int MODE, typename T, int ACT = -1, int RPT = 4>  // 0: (y, y^2)   1: (dz, dz*xhat)
 __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y, int ldy,
                                                         const T* __restrict__ dout, int lddout,
                                                         long long M, int C, const float* __restrict__ coef,
-                                                        int act, float* __restrict__ part, int nparts, int cpb,
+                                                        int act_rt, float* __restrict__ part, int nparts, int cpb,
                                                         int ppg, long long Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   // rows are split into groups of Rg rows (independent BatchNorm batches); part p covers a row chunk of
   // group p / ppg and uses that group's coefficients
   __shared__ f32x4 sh[2][256];
@@ -121,16 +124,16 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const T* __restrict__ y,
     if (MODE == 1) { mean = ld4(coef + quad * 4); invstd = ld4(coef + C + quad * 4); }
     // four rows per trip: their loads are issued together (one row per trip left ~2 loads per lane in flight: 2.9 TB/s)
     long long row = r0 + rl;
-    for (; row + 3 * rpb < r1; row += 4 * rpb) {
-      f32x4 yv[4], dz[4];
+    for (; row + (RPT - 1) * rpb < r1; row += RPT * rpb) {
+      f32x4 yv[RPT], dz[RPT];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) yv[u] = ld4(y + (row + u * rpb) * ldy + quad * 4);
+      for (int u = 0; u < RPT; ++u) yv[u] = ld4(y + (row + u * rpb) * ldy + quad * 4);
       if (MODE == 1) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) dz[u] = act_dz(y, dout, lddout, row + u * rpb, C, quad, coef, act, yv[u]);
+        for (int u = 0; u < RPT; ++u) dz[u] = act_dz(y, dout, lddout, row + u * rpb, C, quad, coef, act, yv[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RPT; ++u) {
         if (MODE == 0) {
           s0 += yv[u];
           s1 += yv[u] * yv[u];
@@ -348,11 +351,12 @@ __global__ void bn_eval_coeffs_kernel(int C, const float* __restrict__ gamma, co
   out[3 * C + c] = beta[c] - rmean[c] * sc;
 }
 
-template <typename T>
+template <typename T, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y, long long M, int C,
-                                                         const float* __restrict__ coef0, int act,
+                                                         const float* __restrict__ coef0, int act_rt,
                                                          const T* __restrict__ residual,
                                                          T* __restrict__ out, int G, unsigned Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
   const int Qo = Cout / 4;
   const long long total = M * Qo;
@@ -385,12 +389,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
-template <typename T>
+template <typename T, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restrict__ y,
                                                                const T* __restrict__ dout, int lddout,
                                                                long long M, int C, const float* __restrict__ coef0,
-                                                               const float* __restrict__ red20, int act,
+                                                               const float* __restrict__ red20, int act_rt,
                                                                T* __restrict__ dy, int G, unsigned Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int Q = C / 4;
   const long long total = M * Q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -414,10 +419,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   }
 }
 
-template <typename T>
+template <typename T, int ACT = -1>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ out, const T* __restrict__ dout,
-                                                      int lddout, long long M, int C, int act,
+                                                      int lddout, long long M, int C, int act_rt,
                                                       T* __restrict__ dy) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int Q = C / 4;
   const long long total = M * Q;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -1158,11 +1164,12 @@ __device__ __forceinline__ RowSpan row_span(long long M, int ppg, long long Rg) 
   return s;
 }
 
-template <typename T, int V>
+template <typename T, int V, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const T* __restrict__ y, long long M, int C,
-                                                              const float* __restrict__ coef0, int act,
+                                                              const float* __restrict__ coef0, int act_rt,
                                                               const T* __restrict__ residual, T* __restrict__ out,
                                                               int lgc, int ppg, long long Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int cpb = 1 << lgc, rpb = 256 >> lgc;
   const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
   const bool glu = act == S2I_ACT_GLU;
@@ -1237,12 +1244,13 @@ __device__ __forceinline__ void row_dz(int act, const BnCo<V>& ca, const BnCo<V>
     }
 }
 
-template <typename T, int V>
+template <typename T, int V, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
                                                                     int lddout, long long M, int C,
                                                                     const float* __restrict__ coef0,
-                                                                    const float* __restrict__ red20, int act,
+                                                                    const float* __restrict__ red20, int act_rt,
                                                                     T* __restrict__ dy, int lgc, int ppg, long long Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   const int cpb = 1 << lgc, rpb = 256 >> lgc;
   const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
   const bool glu = act == S2I_ACT_GLU;
@@ -1292,12 +1300,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_rows_kernel(const T* __r
 }
 
 // column sums of (dz, dz * xhat) over this block's rows: part[0 / 1][blockIdx.x][C], as colreduce_kernel<1>
-template <typename T, int V>
+template <typename T, int V, int ACT = -1>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
                                                                      int lddout, long long M, int C,
-                                                                     const float* __restrict__ coef0, int act,
+                                                                     const float* __restrict__ coef0, int act_rt,
                                                                      float* __restrict__ part, int nparts, int lgc, int ppg,
                                                                      long long Rg) {
+  const int act = ACT >= 0 ? ACT : act_rt;
   constexpr int NQ = V / 4;
   __shared__ f32x4 sh[4 * NQ][256];                     // [sum index][thread]
   const int cpb = 1 << lgc, rpb = 256 >> lgc;
@@ -1522,21 +1531,30 @@ static int bn_act_forward_impl(const T* y, long long M, int groups, int C, const
   constexpr bool is16 = sizeof(T) == 2;
   const bool rows_on = (ew_rows_mask() & 1) != 0 && (is16 || (ew_rows_mask() & 16) != 0);   // fp32: no gain (bit 4 forces it)
   if (rows_on) {
+#define S2I_FWDR(VV, ACTV) hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, VV, ACTV>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, \
+                                              y, M, C, coef4, act, residual, out, g.lgc, g.ppg, M / groups)
     if (is16 && (Cout % 8) == 0) {
       const RowGeom g = row_geom(Cout / 8, M / groups, groups, 0);
-      hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, 8>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, M, C, coef4, act,
-                         residual, out, g.lgc, g.ppg, M / groups);
+      if (act == S2I_ACT_GLU) S2I_FWDR(8, S2I_ACT_GLU);
+      else if (act == S2I_ACT_LRELU) S2I_FWDR(8, S2I_ACT_LRELU);
+      else if (act == S2I_ACT_NONE) S2I_FWDR(8, S2I_ACT_NONE);
+      else S2I_FWDR(8, -1);
     } else {
       const RowGeom g = row_geom(Cout / 4, M / groups, groups, 0);
-      hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, 4>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, M, C, coef4, act,
-                         residual, out, g.lgc, g.ppg, M / groups);
+      S2I_FWDR(4, -1);
     }
+#undef S2I_FWDR
     S2I_LAUNCH_CHECK("bn_act_forward(rows)");
     return 0;
   }
   const long long total = M * (Cout / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, act, residual, out,
-                     groups, (unsigned)(M / groups));
+#define S2I_FWD(ACTV) hipLaunchKernelGGL((bn_act_fwd_kernel<T, ACTV>), dim3(grid_for(total)), dim3(256), 0, ST, y, M, C, coef4, \
+                                         act, residual, out, groups, (unsigned)(M / groups))
+  if (act == S2I_ACT_GLU) S2I_FWD(S2I_ACT_GLU);
+  else if (act == S2I_ACT_LRELU) S2I_FWD(S2I_ACT_LRELU);
+  else if (act == S2I_ACT_NONE) S2I_FWD(S2I_ACT_NONE);
+  else S2I_FWD(-1);
+#undef S2I_FWD
   S2I_LAUNCH_CHECK("bn_act_forward");
   return 0;
 }
@@ -1562,21 +1580,33 @@ static int bn_act_bwd_reduce_impl(const T* y, const T* dout, int lddout, long lo
   const bool rows_on = (ew_rows_mask() & 2) != 0;
   if (rows_on) {
     const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
+#define S2I_REDR(VV, ACTV) hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, VV, ACTV>), dim3(nparts, g.gy), dim3(256), 0, ST, y, \
+                                              dout, lddout, M, C, coef4, act, part, nparts, g.lgc, g.ppg, M / groups)
     if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
       const RowGeom g = row_geom(Ch / 8, M / groups, groups, nparts / groups);
-      hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, 8>), dim3(nparts, g.gy), dim3(256), 0, ST, y, dout, lddout, M, C,
-                         coef4, act, part, nparts, g.lgc, g.ppg, M / groups);
+      if (act == S2I_ACT_GLU) S2I_REDR(8, S2I_ACT_GLU);
+      else if (act == S2I_ACT_LRELU) S2I_REDR(8, S2I_ACT_LRELU);
+      else S2I_REDR(8, -1);
     } else {
       const RowGeom g = row_geom(Ch / 4, M / groups, groups, nparts / groups);
-      hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, 4>), dim3(nparts, g.gy), dim3(256), 0, ST, y, dout, lddout, M, C,
-                         coef4, act, part, nparts, g.lgc, g.ppg, M / groups);
+      if (act == S2I_ACT_GLU) S2I_REDR(4, S2I_ACT_GLU);
+      else if (act == S2I_ACT_LRELU) S2I_REDR(4, S2I_ACT_LRELU);
+      else S2I_REDR(4, -1);
     }
+#undef S2I_REDR
     S2I_LAUNCH_CHECK("bn_act_bwd_reduce(rows)");
     return 0;
   }
   RedGeom g = red_geom(C);
-  hipLaunchKernelGGL((colreduce_kernel<1, T>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, dout, lddout, M, C, coef4,
-                     act, part, nparts, g.cpb, nparts / groups, M / groups);
+  // the activation as a template constant (S2I_EW_SPEC=0: the runtime form, for comparison): see colreduce_kernel
+  const bool spec = !(getenv("S2I_EW_SPEC") && atoi(getenv("S2I_EW_SPEC")) == 0);
+#define S2I_RED(ACTV) hipLaunchKernelGGL((colreduce_kernel<1, T, ACTV, 4>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, \
+                                         dout, lddout, M, C, coef4, act, part, nparts, g.cpb, nparts / groups, M / groups)
+  if (spec && act == S2I_ACT_LRELU) S2I_RED(S2I_ACT_LRELU);
+  else if (spec && act == S2I_ACT_GLU) S2I_RED(S2I_ACT_GLU);
+  else if (spec && act == S2I_ACT_NONE) S2I_RED(S2I_ACT_NONE);
+  else S2I_RED(-1);
+#undef S2I_RED
   S2I_LAUNCH_CHECK("bn_act_bwd_reduce");
   return 0;
 }
@@ -1608,20 +1638,30 @@ static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long lon
   const bool rows_on = (ew_rows_mask() & 4) != 0;
   if (rows_on) {
     const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
+#define S2I_APPR(VV, ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, VV, ACTV>), dim3(groups * g.ppg, g.gy), dim3(256), 0, \
+                                              ST, y, dout, lddout, M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups)
     if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
       const RowGeom g = row_geom(Ch / 8, M / groups, groups, 0);
-      hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, 8>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, dout, lddout,
-                         M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups);
+      if (act == S2I_ACT_GLU) S2I_APPR(8, S2I_ACT_GLU);
+      else if (act == S2I_ACT_LRELU) S2I_APPR(8, S2I_ACT_LRELU);
+      else S2I_APPR(8, -1);
     } else {
       const RowGeom g = row_geom(Ch / 4, M / groups, groups, 0);
-      hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, 4>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, y, dout, lddout,
-                         M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups);
+      if (act == S2I_ACT_GLU) S2I_APPR(4, S2I_ACT_GLU);
+      else if (act == S2I_ACT_LRELU) S2I_APPR(4, S2I_ACT_LRELU);
+      else S2I_APPR(4, -1);
     }
+#undef S2I_APPR
     S2I_LAUNCH_CHECK("bn_act_bwd_apply(rows)");
     return 0;
   }
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, lddout, M, C,
-                     coef4, red2, act, dy, groups, (unsigned)(M / groups));
+#define S2I_APP(ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, ACTV>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, \
+                                         lddout, M, C, coef4, red2, act, dy, groups, (unsigned)(M / groups))
+  if (act == S2I_ACT_GLU) S2I_APP(S2I_ACT_GLU);
+  else if (act == S2I_ACT_LRELU) S2I_APP(S2I_ACT_LRELU);
+  else if (act == S2I_ACT_NONE) S2I_APP(S2I_ACT_NONE);
+  else S2I_APP(-1);
+#undef S2I_APP
   S2I_LAUNCH_CHECK("bn_act_bwd_apply");
   return 0;
 }
@@ -1654,7 +1694,12 @@ static int act_backward_impl(const T* out, const T* dout, int lddout, long long 
     S2I_LAUNCH_CHECK("act_backward(rows)");
     return 0;
   }
-  hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
+  if (act == S2I_ACT_LRELU)
+    hipLaunchKernelGGL((act_bwd_kernel<T, S2I_ACT_LRELU>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
+  else if (act == S2I_ACT_TANH)
+    hipLaunchKernelGGL((act_bwd_kernel<T, S2I_ACT_TANH>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
+  else
+    hipLaunchKernelGGL((act_bwd_kernel<T, -1>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
   S2I_LAUNCH_CHECK("act_backward");
   return 0;
 }
