@@ -419,6 +419,82 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const T* __restri
   }
 }
 
+// The backward apply as a WALKER (round 2): a thread keeps one channel quad and walks the rows of its block's chunk, as
+// colreduce_kernel does, with EVERY coefficient in registers (loaded by hand before the row loop: the stores to dy inside
+// the loop keep the compiler from hoisting them).  The grid-stride form above re-loads seven to nine 16-byte coefficient
+// vectors per quad -- L1 hits, but 168 bytes through the CU's 64 B/clk vector-memory path for 24 bytes of data: on the
+// 32-channel GLU tensors of the generator that path, not HBM, set the 2.3 TB/s.
+template <typename T, int ACT, int RPT = 4>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_walk_kernel(const T* __restrict__ y, const T* __restrict__ dout,
+                                                                    int lddout, long long M, int C,
+                                                                    const float* __restrict__ coef0,
+                                                                    const float* __restrict__ red20, T* __restrict__ dy,
+                                                                    int cpb, int ppg, long long Rg) {
+  const int tid = threadIdx.x;
+  const int rpb = 256 / cpb;
+  const int ql = tid % cpb, rl = tid / cpb;
+  const int quad = blockIdx.y * cpb + ql;
+  if (quad >= C / 4) return;
+  const int grp = blockIdx.x / ppg, pp = blockIdx.x - grp * ppg;
+  const long long chunk = (Rg + ppg - 1) / ppg;
+  const long long r0 = grp * Rg + pp * chunk;
+  const long long gend = (grp + 1) * Rg < M ? (grp + 1) * Rg : M;
+  const long long r1 = r0 + chunk < gend ? r0 + chunk : gend;
+  const float* coef = coef0 + (size_t)grp * 4 * C;
+  const float* red2 = red20 + (size_t)grp * 2 * C;
+  const float* scale = coef + 2 * C;
+  const float* shift = coef + 3 * C;
+  const f32x4 mean = ld4(coef + quad * 4), invstd = ld4(coef + C + quad * 4), sc = ld4(scale + quad * 4);
+  const f32x4 sh = ld4(shift + quad * 4);
+  const f32x4 m0 = ld4(red2 + quad * 4), m1 = ld4(red2 + C + quad * 4);
+  // GLU: this quad is in the value half (first) or the gate half; pq is its partner quad in the other half
+  const int hq = C / 8;
+  const bool first = quad < hq;
+  const int pq = ACT == S2I_ACT_GLU ? (first ? quad + hq : quad - hq) : quad;
+  const int dq = ACT == S2I_ACT_GLU ? (first ? quad : pq) : quad;          // quad of dout
+  f32x4 sp = sc, tp = sh;                                                   // partner's scale / shift
+  if (ACT == S2I_ACT_GLU) { sp = ld4(scale + pq * 4); tp = ld4(shift + pq * 4); }
+  auto finish = [&](long long row, const f32x4& yv, const f32x4& yp, const f32x4& d) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float dz;
+      if (ACT == S2I_ACT_GLU) {
+        // value half: dz = d * sigmoid(gate);  gate half: dz = d * value * sigmoid(gate) * (1 - sigmoid(gate))
+        const float za = first ? sc[j] * yv[j] + sh[j] : sp[j] * yp[j] + tp[j];
+        const float zg = first ? sp[j] * yp[j] + tp[j] : sc[j] * yv[j] + sh[j];
+        const float sgm = sigmoid_gate_<T>(zg);
+        dz = first ? d[j] * sgm : d[j] * za * sgm * (1.f - sgm);
+      } else if (ACT == S2I_ACT_LRELU) {
+        dz = (sc[j] * yv[j] + sh[j]) > 0.f ? d[j] : 0.2f * d[j];
+      } else {
+        dz = d[j];
+      }
+      const float xh = (yv[j] - mean[j]) * invstd[j];
+      o[j] = sc[j] * (dz - m0[j] - xh * m1[j]);
+    }
+    st4(dy + row * C + quad * 4, o);
+  };
+  long long row = r0 + rl;
+  for (; row + (RPT - 1) * rpb < r1; row += RPT * rpb) {
+    f32x4 yv[RPT], yp[RPT], d[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+      yv[u] = ld4(y + (row + u * rpb) * C + quad * 4);
+      d[u] = ld4(dout + (row + u * rpb) * lddout + dq * 4);
+      yp[u] = ACT == S2I_ACT_GLU ? ld4(y + (row + u * rpb) * C + pq * 4) : yv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) finish(row + u * rpb, yv[u], yp[u], d[u]);
+  }
+  for (; row < r1; row += rpb) {
+    const f32x4 yv = ld4(y + row * C + quad * 4);
+    const f32x4 d = ld4(dout + row * lddout + dq * 4);
+    const f32x4 yp = ACT == S2I_ACT_GLU ? ld4(y + row * C + pq * 4) : yv;
+    finish(row, yv, yp, d);
+  }
+}
+
 template <typename T, int ACT = -1>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ out, const T* __restrict__ dout,
                                                       int lddout, long long M, int C, int act_rt,
@@ -1653,6 +1729,24 @@ static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long lon
     }
 #undef S2I_APPR
     S2I_LAUNCH_CHECK("bn_act_bwd_apply(rows)");
+    return 0;
+  }
+  if (!(getenv("S2I_EW_WALK") && atoi(getenv("S2I_EW_WALK")) == 0) &&
+      (act == S2I_ACT_GLU || act == S2I_ACT_LRELU || act == S2I_ACT_NONE)) {
+    RedGeom g = red_geom(C);
+    const long long Rg = M / groups;
+    const int rpb = 256 / g.cpb;
+    long long ppg = (Rg + (long long)rpb * 16 - 1) / ((long long)rpb * 16);     // >= 16 rows per thread where the tensor allows
+    const long long cap = 4096 / ((long long)groups * g.gy) > 0 ? 4096 / ((long long)groups * g.gy) : 1;
+    if (ppg > cap) ppg = cap;
+    if (ppg < 1) ppg = 1;
+#define S2I_APPW(ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_walk_kernel<T, ACTV>), dim3(groups * (int)ppg, g.gy), dim3(256), 0, ST, y, \
+                                          dout, lddout, M, C, coef4, red2, dy, g.cpb, (int)ppg, Rg)
+    if (act == S2I_ACT_GLU) S2I_APPW(S2I_ACT_GLU);
+    else if (act == S2I_ACT_LRELU) S2I_APPW(S2I_ACT_LRELU);
+    else S2I_APPW(S2I_ACT_NONE);
+#undef S2I_APPW
+    S2I_LAUNCH_CHECK("bn_act_bwd_apply(walk)");
     return 0;
   }
 #define S2I_APP(ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, ACTV>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, y, dout, \
