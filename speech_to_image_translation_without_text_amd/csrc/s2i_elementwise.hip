@@ -1496,6 +1496,21 @@ static int ew_rows_mask() {
 
 // host geometry of the row-tiled kernels: threads across the channel vectors (a power of two), the rest of the block
 // down the rows; enough blocks along the rows to keep ~16 waves per CU busy with at least a few trips each
+// blocks along the rows of one BatchNorm group: `want` rows per thread where the tensor is large, but never so few blocks
+// that the chip is under-filled (small tensors: down to one row per thread -- a short kernel is all latency, and a
+// thread that walks 8 rows one pair at a time takes four memory round trips where one would do), at most 4096 blocks
+static int rows_ppg(long long Rg, int rpb, int groups, int gy, int want) {
+  const long long per = (long long)groups * gy;
+  long long ppg = (Rg + (long long)rpb * want - 1) / ((long long)rpb * want);
+  const long long fill = (2048 + per - 1) / per;
+  if (ppg < fill) ppg = fill;
+  const long long most = (Rg + rpb - 1) / rpb;               // one row per thread
+  if (ppg > most) ppg = most;
+  const long long cap = 4096 / per > 0 ? 4096 / per : 1;
+  if (ppg > cap) ppg = cap;
+  if (ppg < 1) ppg = 1;
+  return (int)ppg;
+}
 struct RowGeom { int lgc, gy, ppg; };
 static RowGeom row_geom(int nvec, long long Rg, int groups, int want_parts) {
   RowGeom g;
@@ -1504,11 +1519,7 @@ static RowGeom row_geom(int nvec, long long Rg, int groups, int want_parts) {
   const int cpb = 1 << g.lgc, rpb = 256 / cpb;
   g.gy = (nvec + cpb - 1) / cpb;
   if (want_parts > 0) { g.ppg = want_parts; return g; }
-  long long ppg = (Rg + (long long)rpb * 8 - 1) / ((long long)rpb * 8);   // >= 8 rows per thread where the tensor allows
-  const long long cap = 4096 / ((long long)groups * g.gy) > 0 ? 4096 / ((long long)groups * g.gy) : 1;
-  if (ppg > cap) ppg = cap;
-  if (ppg < 1) ppg = 1;
-  g.ppg = (int)ppg;
+  g.ppg = rows_ppg(Rg, rpb, groups, g.gy, 8);
   return g;
 }
 
@@ -1736,12 +1747,9 @@ static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long lon
     RedGeom g = red_geom(C);
     const long long Rg = M / groups;
     const int rpb = 256 / g.cpb;
-    long long ppg = (Rg + (long long)rpb * 16 - 1) / ((long long)rpb * 16);     // >= 16 rows per thread where the tensor allows
-    const long long cap = 4096 / ((long long)groups * g.gy) > 0 ? 4096 / ((long long)groups * g.gy) : 1;
-    if (ppg > cap) ppg = cap;
-    if (ppg < 1) ppg = 1;
-#define S2I_APPW(ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_walk_kernel<T, ACTV>), dim3(groups * (int)ppg, g.gy), dim3(256), 0, ST, y, \
-                                          dout, lddout, M, C, coef4, red2, dy, g.cpb, (int)ppg, Rg)
+    const int ppg = rows_ppg(Rg, rpb, groups, g.gy, 16);
+#define S2I_APPW(ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_walk_kernel<T, ACTV>), dim3(groups * ppg, g.gy), dim3(256), 0, ST, y, \
+                                          dout, lddout, M, C, coef4, red2, dy, g.cpb, ppg, Rg)
     if (act == S2I_ACT_GLU) S2I_APPW(S2I_ACT_GLU);
     else if (act == S2I_ACT_LRELU) S2I_APPW(S2I_ACT_LRELU);
     else S2I_APPW(S2I_ACT_NONE);
