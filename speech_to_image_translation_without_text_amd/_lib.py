@@ -181,5 +181,13 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = torch.cuda.current_device
+
+
 def stream():
+    """Raw hipStream_t of torch's current stream.  `torch.cuda.current_stream().cuda_stream` builds a Stream object per
+    call (8 us; 1 600 calls per train step = 2.6 ms of host time, tools/host_profile.py); the raw query is ~0.3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
