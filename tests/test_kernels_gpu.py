@@ -375,3 +375,60 @@ def test_split_bf16_products_against_fp64(gpu):
             assert e3 <= 1.5 * e0 + 1e-9, cerr
     finally:
         ops.MATH_PLANES = old
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("act", ["none", "glu", "lrelu"])
+def test_batchnorm_pass_forms_agree(gpu, act, dtype, monkeypatch):
+    """The BatchNorm / activation passes exist in several forms (activation as a template constant vs a runtime switch,
+    row walker vs grid-stride apply, row-tiled vs flat forward: DESIGN.md section 11).  On the same inputs the specialised
+    backward reduce must equal the runtime form bit for bit (same operations in the same order), the other pairs within
+    float rounding of a differently contracted expression."""
+    import ctypes
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import ACT_GLU, ACT_LRELU, ACT_NONE, DT_BF16, DT_F32, check, ptr, stream
+    lib = ops._lib_ready()
+    a = {"none": ACT_NONE, "glu": ACT_GLU, "lrelu": ACT_LRELU}[act]
+    dt, tdt = (DT_F32, torch.float32) if dtype == "f32" else (DT_BF16, torch.bfloat16)
+    g = torch.Generator(device=gpu).manual_seed(3)
+    G, M, C = 3, 3 * 520, 64                   # 520 rows per group: not a multiple of any block's row count
+    Co = C // 2 if a == ACT_GLU else C
+    y = torch.randn(M, C, device=gpu, generator=g).to(tdt)
+    dout = torch.randn(M, Co, device=gpu, generator=g).to(tdt)
+    coef = torch.randn(G, 4, C, device=gpu, generator=g)
+    coef[:, 1].abs_().add_(0.5)
+    red2 = torch.randn(G, 2, C, device=gpu, generator=g) * 0.1
+    nparts = 4 * G
+
+    def reduce_():
+        part = torch.zeros(2, nparts, C, device=gpu)
+        check(lib.s2i_bn_act_bwd_reduce_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), a, ptr(part), nparts, stream()), "reduce")
+        return part
+
+    def apply_():
+        dy = torch.empty(M, C, device=gpu, dtype=tdt)
+        check(lib.s2i_bn_act_bwd_apply_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), ptr(red2), a, ptr(dy), stream()), "apply")
+        return dy.float()
+
+    def forward_():
+        out = torch.empty(M, Co, device=gpu, dtype=tdt)
+        check(lib.s2i_bn_act_forward_dt(dt, ptr(y), M, G, C, ptr(coef), a, None, ptr(out), stream()), "forward")
+        return out.float()
+
+    results = {}
+    for name, env in (("default", {}), ("runtime", {"S2I_EW_SPEC": "0", "S2I_EW_WALK": "0", "S2I_EW_ROWS": "0"}),
+                      ("rows", {"S2I_EW_ROWS": "31", "S2I_EW_WALK": "0"})):
+        for k in ("S2I_EW_SPEC", "S2I_EW_WALK", "S2I_EW_ROWS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        results[name] = (reduce_(), apply_(), forward_())
+    torch.cuda.synchronize()
+    assert torch.equal(results["default"][0], results["runtime"][0]), "specialised backward reduce differs from the runtime form"
+    tol = 2e-2 if dtype == "bf16" else 1e-5    # bf16: a final rounding may fall the other way
+    for i, what in ((0, "reduce"), (1, "apply"), (2, "forward")):
+        for other in ("runtime", "rows"):
+            ref, got = results["default"][i], results[other][i]
+            scale = float(ref.abs().max()) + 1e-12
+            assert float((ref - got).abs().max()) <= tol * scale, (what, other, float((ref - got).abs().max()), scale)
