@@ -557,6 +557,9 @@ def _dgrad(kind_name, dy, w, packed, n_in, out_dtype=None):
     return y
 
 
+RGB_WGRAD_MFMA = os.environ.get("S2I_RGB_WGRAD", "1") != "0"
+
+
 def _wgrad(kind_name, x, cvec, dy, weight):
     """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode."""
     out, acc = (weight.grad, True) if _direct(weight) else (None, False)
@@ -567,7 +570,15 @@ def _wgrad(kind_name, x, cvec, dy, weight):
                 raise _lib.S2IError("wgrad: bf16 operands carry their broadcast vector materialised")
             if kind_name == "up":
                 return wgrad_any(CONV_K4S2, dy, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
-            return wgrad_any(_KIND[kind_name], x, dy, tuple(weight.shape), out=out, accumulate=acc)
+            g = dy
+            if (RGB_WGRAD_MFMA and x.dtype == torch.bfloat16 and dy.dtype == torch.float32 and dy.shape[-1] <= 4
+                    and x.shape[-1] % 8 == 0):
+                # GET_IMAGE_G's weight gradient (bf16 features x fp32 NHWC4 image gradient): the <= 4 channel stream kernel
+                # ran at a tenth of the HBM rate (0.32 ms at 256 px); padded to 8 bf16 channels the image gradient goes
+                # through the bf16-MFMA weight-gradient kernel like every other layer's
+                g = torch.zeros(dy.shape[:-1] + (8,), dtype=torch.bfloat16, device=dy.device)
+                g[..., :dy.shape[-1]] = dy
+            return wgrad_any(_KIND[kind_name], x, g, tuple(weight.shape), out=out, accumulate=acc)
         if kind_name == "up":
             return wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
         return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
