@@ -104,7 +104,7 @@ class _Workspace:
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 16)
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, stream())     # the raw query: a Stream object per scratch request cost 8 us (tools/host_profile.py)
         cur = self.buf.get(key)
         if cur is None or cur.numel() * 4 < nbytes:
             # during hipGraph capture the allocation comes from the graph's private pool and stays reserved for it
