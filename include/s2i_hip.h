@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S2I_ABI_VERSION 2
+#define S2I_ABI_VERSION 3
 
 /* conv geometry kinds */
 #define S2I_CONV_K1      0  /* 1x1 / nn.Linear (model.py:179, 217)                              */
@@ -56,6 +56,11 @@ extern "C" {
 
 const char* s2i_last_error(void);
 int  s2i_version(void);
+/* Integer tuning knobs of the launch planners (tools and tests; every knob has a measured default).  Returns 0, or
+   non-zero for an unknown key.  The library reads no environment variable on a launch path: the ONE variable
+   S2I_TUNE="key=value,key=value" is parsed once, when the library is loaded. */
+int  s2i_set_tuning(const char* key, int value);
+int  s2i_get_tuning(const char* key, int* value);
 /* 0 when the current device is gfx950, non-zero (and last_error set) otherwise */
 int  s2i_check_device(void);
 
@@ -79,6 +84,8 @@ typedef struct s2i_conv_desc {
                     statistics are kept per group.  0 or 1 = one batch                           */
   int nosplit;   /* 1: never split K (required with a class bias, s2i_conv_forward_cls)           */
   int kw, stride, pad; /* S2I_CONV_1D geometry (ignored by the other kinds)                       */
+  int tile_rows; /* output rows per block of the fp32 matrix kernel: 0 = the planner chooses (96 or 128, whichever
+                    fills whole rounds of the chip's block slots); 96 or 128 forces it (96 only where N > 64)     */
 } s2i_conv_desc;
 
 /* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */

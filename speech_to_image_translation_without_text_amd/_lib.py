@@ -17,7 +17,7 @@ CONV_K1, CONV_K3S1, CONV_K4S2, TCONV_K4S2, CONV_1D = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
 PACK_PLAIN, PACK_UPFOLD = 0, 1
 DT_F32, DT_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_longlong)
@@ -25,7 +25,8 @@ c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes
 
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Cx", "Cc", "N", "wmode", "flip", "wR",
-                                     "ldw", "act", "stats", "ldy", "groups", "nosplit", "kw", "stride", "pad")]
+                                     "ldw", "act", "stats", "ldy", "groups", "nosplit", "kw", "stride", "pad",
+                                     "tile_rows")]
 
 
 class WgradDesc(ctypes.Structure):
@@ -48,6 +49,8 @@ _SIGNATURES = {
     "s2i_last_error": (ctypes.c_char_p, []),
     "s2i_version": (c_int, []),
     "s2i_check_device": (c_int, []),
+    "s2i_set_tuning": (c_int, [ctypes.c_char_p, c_int]),
+    "s2i_get_tuning": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
     "s2i_conv_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, c_size_t, P]),
@@ -159,6 +162,30 @@ def check(rc, what):
     if rc != 0:
         msg = load().s2i_last_error()
         raise S2IError("%s failed: %s" % (what, msg.decode() if msg else "unknown error"))
+
+
+class tuning:
+    """`with tuning(fwd_bm=96): ...` sets integer knobs of the launch planners (s2i_set_tuning) for the body and restores
+    them: tools and tests use it to force a kernel variant; nothing on a launch path reads the environment."""
+
+    def __init__(self, **knobs):
+        self.knobs = knobs
+
+    def __enter__(self):
+        lib = load()
+        self.old = {}
+        for k, v in self.knobs.items():
+            cur = c_int(0)
+            check(lib.s2i_get_tuning(k.encode(), ctypes.byref(cur)), "s2i_get_tuning")
+            self.old[k] = cur.value
+            check(lib.s2i_set_tuning(k.encode(), int(v)), "s2i_set_tuning")
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k, v in self.old.items():
+            check(lib.s2i_set_tuning(k.encode(), v), "s2i_set_tuning")
+        return False
 
 
 def require_device():

@@ -34,3 +34,13 @@ static inline int s2i_ilog2(int v) {
 }
 static inline bool s2i_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int s2i_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- tuning knobs (s2i_set_tuning / S2I_TUNE, parsed once at load; s2i_runtime.hip) ----
+enum {
+  S2I_TUNE_FWD_BM = 0,      // fwd_bm: force the tile height of the fp32 matrix kernel (0 = planner)
+  S2I_TUNE_FWD_MIN_CPS,     // fwd_min_cps: fewest 32-deep K chunks a split-K block keeps
+  S2I_TUNE_B16_V2,          // b16_v2: 0 never / 1 where eligible and >= 224 tiles / 2 wherever eligible
+  S2I_TUNE_B16_PERSIST,     // b16_persist: 0 off / 1 one block per CU / n block slots (tests)
+  S2I_TUNE_COUNT
+};
+int s2i_tune(int key, int def);

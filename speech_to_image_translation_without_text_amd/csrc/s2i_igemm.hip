@@ -178,7 +178,11 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   constexpr int ASLOTS = BM / 32;
   constexpr int BSLOTS = BN / 32;
   constexpr int BROWS_PER_PASS = 1024 / BN;
-  __shared__ __attribute__((aligned(16))) float smem[32 * LDA + 32 * LDB + 4];
+  // 96-row tiles are padded to the LDS footprint of a 128-row tile: exactly three blocks per CU either way, so that
+  // 768 blocks are one round of the chip for both (plan_fwd counts rounds)
+  constexpr int SMEM_FLOATS = 32 * LDA + 32 * LDB + 4;
+  constexpr int SMEM_MIN = BM < 128 ? 32 * 129 + 32 * LDB + 4 : 0;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS > SMEM_MIN ? SMEM_FLOATS : SMEM_MIN];
   float* As = smem + (WT ? 0 : 32 * LDB);  // keep the b128-written array 16-byte aligned
   float* Bs = smem + (WT ? 32 * LDA : 0);
 
@@ -1998,9 +2002,21 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const s2i_pack
 
 // ---- host-side planning ------------------------------------------------------------------------
 struct FwdPlan {
-  int T, K, Ca, Ho, Wo, M, nphases, tile, gridM, gridN, nchunks, splitk, cps;
+  int T, K, Ca, Ho, Wo, M, nphases, tile, bm, gridM, gridN, nchunks, splitk, cps;
   long long Mrows;
 };
+
+// K split of a launch of `blocks` output tiles: three 256-thread blocks fit per CU, so split K until about 768 blocks exist
+static int fwd_splitk(long long blocks, int nchunks, int nosplit, int min_cps) {
+  int splitk = 1;
+  if (blocks < 512 && nchunks >= 16 && !nosplit) {
+    splitk = (int)(768 / blocks);
+    if (splitk > nchunks / min_cps) splitk = nchunks / min_cps;
+    if (splitk > 64) splitk = 64;
+    if (splitk < 1) splitk = 1;
+  }
+  return splitk;
+}
 
 int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "conv: non-positive extent");
@@ -2039,50 +2055,52 @@ int plan_fwd(const s2i_conv_desc* d, FwdPlan* pl) {
   S2I_REQUIRE(d->ldy >= d->N, "conv: ldy < N");
   S2I_REQUIRE(!(d->stats && (d->act != S2I_ACT_NONE)), "conv: stats epilogue needs act NONE");
   if (d->stats && d->groups > 1) {
-    // independent BatchNorm batches stacked along the rows: a 128-row tile must not straddle two of them
-    S2I_REQUIRE(d->kind != S2I_TCONV_K4S2 && (M % d->groups) == 0 && ((M / d->groups) % 128) == 0,
-                "conv: %lld rows do not split into %d BatchNorm groups of whole 128-row tiles", M, d->groups);
+    // independent BatchNorm batches stacked along the rows: a row tile must not straddle two of them (tile heights are
+    // checked per candidate below; 96-row tiles exist only for N > 64)
+    S2I_REQUIRE(d->kind != S2I_TCONV_K4S2 && (M % d->groups) == 0 &&
+                    (((M / d->groups) % 128) == 0 || (d->N > 64 && ((M / d->groups) % 96) == 0 && d->tile_rows != 128)),
+                "conv: %lld rows do not split into %d BatchNorm groups of whole row tiles", M, d->groups);
     S2I_REQUIRE((d->N % 4) == 0, "conv: grouped statistics need N %% 4 == 0");
   }
   pl->tile = d->N > 64 ? 0 : (d->N > 32 ? 1 : 2);
   const int BN = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
-  pl->gridM = s2i_cdiv(M, 128);
   pl->gridN = s2i_cdiv(d->N, BN);
   pl->nchunks = s2i_cdiv(pl->K, 32);
-  const long long blocks = (long long)pl->gridM * pl->gridN * pl->nphases;
-  int splitk = 1;
-  if (blocks < 512 && pl->nchunks >= 16 && !d->nosplit) {
-    // three 256-thread blocks fit per CU: split K until about 768 blocks exist
-    splitk = (int)(768 / blocks);
-    if (splitk > pl->nchunks / 8) splitk = pl->nchunks / 8;
-    if (splitk > 64) splitk = 64;
-    if (splitk < 1) splitk = 1;
+  // Rows per tile.  The chip holds 768 blocks at a time (three per CU); a launch whose tiles x K-splits fill whole
+  // rounds of them runs at 121 - 125 TFLOP/s, one that ends on 0.5 or 0.75 of a round at ~100
+  // (profiles/r02_f32_per_launch_table.txt).  The discriminators' stacked passes have 72 = 8 x 9 images, so 128-row
+  // tiles give 9 x 2^k of them (576, 1152: 0.75 / 1.5 rounds) where 96-row tiles give 3 x 2^k (768, 1536).  (192 x 128
+  // tiles need 168+ registers: no third block per CU, and at two per CU a round holds the same rows as with 128.)
+  // Candidates are priced as rounds x (chunks per block + a fixed prologue / epilogue share) x rows, the smaller
+  // tile with the measured relative cost of its matrix loop.
+  const int forced_bm = d->tile_rows ? d->tile_rows : s2i_tune(S2I_TUNE_FWD_BM, 0);
+  S2I_REQUIRE(forced_bm == 0 || forced_bm == 96 || forced_bm == 128, "conv: tile_rows must be 0, 96 or 128");
+  const int min_cps = s2i_tune(S2I_TUNE_FWD_MIN_CPS, 4);
+  static const int cand_bm[2] = {128, 96};
+  double best = 1e300;
+  int best_bm = 128, best_split = 1;
+  for (int c = 0; c < 2; ++c) {
+    const int bm = cand_bm[c];
+    if (forced_bm ? bm != forced_bm : false) continue;
+    if (bm == 96 && pl->tile != 0) continue;                       // 96 x 128 only (four waves side by side)
+    if (bm != 128 && (d->kind == S2I_CONV_1D || M < 2 * bm)) continue;
+    if (d->stats && d->groups > 1 && ((M / d->groups) % bm) != 0) continue;
+    const long long blocks = (long long)s2i_cdiv(M, bm) * pl->gridN * pl->nphases;
+    const int sk0 = fwd_splitk(blocks, pl->nchunks, d->nosplit, min_cps);
+    const int cps = s2i_cdiv(pl->nchunks, sk0), sk = s2i_cdiv(pl->nchunks, cps);
+    const double rounds = (double)((blocks * sk + 767) / 768);
+    const double rel = bm == 128 ? 1.0 : 0.80;   // time of one chunk of a block, 128 rows = 1
+    // slab write + read at ~4 TB/s in units of one chunk round of the chip (768 x 128 x 128 x 32 MACs at 122 TFLOP/s = 6.6 us)
+    const double slab = sk > 1 ? 3.0e-7 * sk * (double)pl->Mrows * d->N : 0.0;
+    const double cost = rounds * (cps + 3.0) * rel + slab + (sk > 1 ? 2.0 : 0.0);
+    if (cost < best * (bm == 128 ? 1.0 : 0.97)) { best = cost; best_bm = bm; best_split = sk; }
   }
-  // Round quantisation (round 2; profiles/r02_f32_per_launch_table.txt): launches whose blocks fill whole rounds of the
-  // chip's 768 slots run at 121 - 125 TFLOP/s, 576 or 1152 blocks (0.75 / 1.5 rounds) at 100.  Where K is long, split it so
-  // that blocks x splitk comes close to whole rounds -- if the fp32 slabs (splitk writes + reads of the output at ~4 TB/s)
-  // cost less than the idle slots.  Measured: the launches in question alone go from 98 - 100 to 116 - 120 TFLOP/s (0.6 ms of
-  // the 28.2 ms of matrix launches per step), but the STEP gets slower (32.37 vs 32.17 ms): in the step the idle slots of
-  // one discriminator's launch are filled by the other discriminators' streams, and the split adds slab traffic and a
-  // reduction launch.  Opt-in: S2I_SPLIT_ROUNDS=1.
-  static const bool rounds_on = getenv("S2I_SPLIT_ROUNDS") && atoi(getenv("S2I_SPLIT_ROUNDS")) != 0;
-  if (rounds_on && !d->nosplit && pl->nchunks >= 32 && blocks * splitk >= 256 && d->kind != S2I_CONV_1D) {
-    const int BNt = pl->tile == 0 ? 128 : (pl->tile == 1 ? 64 : 32);
-    // seconds of one full round of unsplit blocks at the measured full-round rate, and of the slab traffic of a split
-    const double t_round = 768.0 * 2.0 * 128.0 * BNt * pl->K / 123e12;
-    const double slab_unit = (double)pl->Mrows * d->N * 4.0 * 2.0 / 4.0e12;   // one slab written + read
-    double best = 1e30;
-    int best_s = splitk;
-    const int cand[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
-    for (int s : cand) {
-      if (s < splitk || s > pl->nchunks / 8) continue;
-      const int cps = s2i_cdiv(pl->nchunks, s), se = s2i_cdiv(pl->nchunks, cps);   // effective split
-      const double rounds = (double)((blocks * se + 767) / 768);
-      const double t = rounds * t_round / se + (se > 1 ? se * slab_unit + 8e-6 : 0.0);
-      if (t < best * 0.97) { best = t; best_s = se; }
-    }
-    splitk = best_s;
-  }
+  S2I_REQUIRE(best < 1e300 || !(d->stats && d->groups > 1 && ((M / d->groups) % 128) != 0),
+              "conv: no tile height fits the %d BatchNorm groups of %lld rows", d->groups, M / (d->groups > 0 ? d->groups : 1));
+  if (best == 1e300) { best_bm = 128; best_split = fwd_splitk((long long)s2i_cdiv(M, 128) * pl->gridN * pl->nphases, pl->nchunks, d->nosplit, min_cps); }
+  pl->bm = best_bm;
+  pl->gridM = s2i_cdiv(M, pl->bm);
+  const int splitk = best_split;
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
   return 0;
@@ -2125,11 +2143,25 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
   pl->gridN = s2i_cdiv(d->N, BN);
   pl->nchunks = s2i_cdiv(M, 32);
   const long long tiles = (long long)pl->gridK * pl->gridN;
-  // three resident blocks per CU hide each other's load latency: aim at one full wave of 3 x 256 blocks
-  int splitk = (int)(768 / tiles);
-  if (splitk > pl->nchunks / 4) splitk = pl->nchunks / 4;
-  if (splitk > 256) splitk = 256;
-  if (splitk < 1) splitk = 1;
+  // three resident blocks per CU hide each other's load latency: split the pixel range so that tiles x splits fill whole
+  // rounds of the chip's 768 block slots (512 tiles x 1 = 0.67 of a round ran at 108 TFLOP/s, profiles/r02_f32_per_launch_table.txt),
+  // priced as rounds x (chunks per block + a fixed share) + the fp32 slabs each split writes and the finish pass reads
+  // (units: one chunk round of the chip, 6.6 us)
+  int splitk = 1;
+  {
+    int smax = pl->nchunks / 4;
+    if (smax > 256) smax = 256;
+    if (smax < 1) smax = 1;
+    double best = 1e300;
+    for (int sc = 1; sc <= smax; ++sc) {
+      const int cps = s2i_cdiv(pl->nchunks, sc), se = s2i_cdiv(pl->nchunks, cps);
+      if (se != sc) continue;                       // same effective split as a smaller candidate
+      const double rounds = (double)((tiles * se + 767) / 768);
+      const double cost = rounds * (cps + 3.0) + 3.0e-7 * se * (double)pl->K * d->N;
+      if (cost < best) { best = cost; splitk = se; }
+      if (tiles * sc > 4 * 768) break;
+    }
+  }
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
   // thin 3x3 layers over wide maps: one kernel row per block, taps read from a staged row segment
@@ -2324,6 +2356,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   p.Mrows = pl.Mrows;
   p.x16 = x16; p.y16 = y16;
   S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
+  S2I_REQUIRE(!wsp || pl.bm == 128, "conv(split): the split-bf16 kernels have 128-row tiles (set tile_rows = 128)");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
   static const bool rgb_on = !(getenv("S2I_RGB") && atoi(getenv("S2I_RGB")) == 0);
   const int rk = (!wsp && !cls_bias && rgb_on) ? rgb_kind(d, pl, x16, y16) : 0;
@@ -2416,7 +2449,8 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     else launch_split<128, 32, 4, 1>(p, grid, planes, st);
     S2I_LAUNCH_CHECK("igemm_fwd_split");
   } else {
-    if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, ca32, st);
+    if (pl.bm == 96) launch_fwd<96, 128, 1, 4>(p, grid, wt, ca32, st);
+    else if (pl.tile == 0) launch_fwd<128, 128, 2, 2>(p, grid, wt, ca32, st);
     else if (pl.tile == 1) launch_fwd<128, 64, 2, 2>(p, grid, wt, ca32, st);
     else launch_fwd<128, 32, 4, 1>(p, grid, wt, ca32, st);
     S2I_LAUNCH_CHECK("igemm_fwd");

@@ -26,3 +26,49 @@ extern "C" int s2i_check_device(void) {
     S2I_FAIL("check_device: kernels are built for gfx950 only, device %d is %s", dev, prop.gcnArchName);
   return 0;
 }
+
+// ---- tuning knobs ----------------------------------------------------------------------------------------------------
+#include <stdlib.h>
+static const char* const g_tune_names[S2I_TUNE_COUNT] = {"fwd_bm", "fwd_min_cps", "b16_v2", "b16_persist"};
+static int g_tune_val[S2I_TUNE_COUNT];
+static bool g_tune_set[S2I_TUNE_COUNT];
+
+static int tune_index(const char* key, size_t len) {
+  for (int i = 0; i < S2I_TUNE_COUNT; ++i)
+    if (strlen(g_tune_names[i]) == len && strncmp(g_tune_names[i], key, len) == 0) return i;
+  return -1;
+}
+
+// S2I_TUNE="key=value,key=value": the library's only environment variable, read once when it is loaded
+namespace {
+struct TuneInit {
+  TuneInit() {
+    const char* e = getenv("S2I_TUNE");
+    while (e && *e) {
+      const char* eq = strchr(e, '=');
+      if (!eq) break;
+      const int i = tune_index(e, (size_t)(eq - e));
+      if (i >= 0) { g_tune_val[i] = atoi(eq + 1); g_tune_set[i] = true; }
+      const char* c = strchr(eq, ',');
+      e = c ? c + 1 : nullptr;
+    }
+  }
+} g_tune_init;
+}  // namespace
+
+int s2i_tune(int key, int def) { return g_tune_set[key] ? g_tune_val[key] : def; }
+
+extern "C" int s2i_set_tuning(const char* key, int value) {
+  const int i = key ? tune_index(key, strlen(key)) : -1;
+  if (i < 0) S2I_FAIL("set_tuning: unknown key '%s'", key ? key : "(null)");
+  g_tune_val[i] = value;
+  g_tune_set[i] = true;
+  return 0;
+}
+
+extern "C" int s2i_get_tuning(const char* key, int* value) {
+  const int i = key ? tune_index(key, strlen(key)) : -1;
+  if (i < 0 || !value) S2I_FAIL("get_tuning: unknown key '%s'", key ? key : "(null)");
+  *value = g_tune_set[i] ? g_tune_val[i] : -1;
+  return 0;
+}

@@ -425,6 +425,10 @@ def _geom(kind, H, W):
     return H, W
 
 
+# rows per block of the fp32 matrix kernel: 0 = the planner's choice; tools / tests set 96 or 128 to force a variant
+TILE_ROWS = 0
+
+
 def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1,
              w_offset=0, cls_bias=None, conv1d=None):
     """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts).
@@ -438,7 +442,7 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
     if conv1d is not None:
         Ho, Wo = H, (W + 2 * pd1 - kw1) // st1 + 1
     d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
-                 1 if cls_bias is not None else 0, kw1, st1, pd1)
+                 1 if cls_bias is not None else 0, kw1, st1, pd1, 128 if MATH_PLANES else TILE_ROWS)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
     if EXEC_LOG is not None:
         T = kw1 if conv1d is not None else _TAPS[kind]

@@ -161,6 +161,48 @@ def test_conv_bn_act_fwd_bwd(gpu, case, math_planes):
     assert int(nbt.item()) == 1
 
 
+TILE96 = [
+    # kind, B, H, Cx, Cout, wmode, groups: 96-row tiles of the fp32 matrix kernel (plan_fwd picks them where 128-row tiles
+    # end on a fraction of a round of the chip; forced here through the descriptor's tile_rows)
+    ("k4s2", 6, 16, 64, 128, 0, 3),     # 384 rows = 4 x 96, three BatchNorm groups of 128 rows... not a multiple of 96 per group
+    ("k4s2", 9, 16, 64, 128, 0, 3),     # 576 rows, groups of 192 = 2 x 96
+    ("k3s1", 3, 16, 32, 256, 0, 1),     # 768 rows, two column tiles
+    ("k3s1", 5, 8, 40, 136, 0, 1),      # ragged: 320 rows (last tile 32 rows), 136 columns, K = 360 (not a multiple of 32)
+    ("tconv", 3, 8, 64, 128, 1, 1),     # input gradient of a stride-2 conv: four phases
+    ("k4s2", 3, 8, 512, 256, 0, 1),     # 48 rows: too few for two tiles -> planner keeps 128 even when 96 is asked
+]
+
+
+@pytest.mark.parametrize("case", TILE96, ids=lambda c: "-".join(str(v) for v in c))
+def test_tile_rows_96_equals_128(gpu, case):
+    """The 96-row tile runs the same K loop per output element as the 128-row tile: results are bit-identical, and the
+    BatchNorm partial sums add up to the same column sums."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K3S1, CONV_K4S2, TCONV_K4S2
+    kind, B, H, Cx, N, wmode, groups = case
+    k = {"k3s1": CONV_K3S1, "k4s2": CONV_K4S2, "tconv": TCONV_K4S2}[kind]
+    T = {"k3s1": 9, "k4s2": 16, "tconv": 16}[kind]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, H, Cx, generator=g).to(gpu)
+    Np = (N + 3) & ~3
+    packed = (torch.randn(T, Cx, Np, generator=g) * 0.05).to(gpu) if not wmode else (torch.randn(T, N, Cx, generator=g) * 0.05).to(gpu)
+    outs = []
+    for rows in (128, 96):
+        ops.TILE_ROWS = rows
+        try:
+            stats = wmode == 0
+            grp_ok = groups == 1 or ((x.shape[0] * (H // 2 if kind == "k4s2" else H) ** 2 // groups) % rows == 0)
+            y, part, nparts = ops.conv_raw(k, x, None, packed, N, wmode=wmode, wR=packed.shape[1], ldw=packed.shape[2],
+                                           stats=stats, groups=groups if grp_ok else 1)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), None if part is None else part.double().sum(1).clone()))
+        finally:
+            ops.TILE_ROWS = 0
+    assert torch.equal(outs[0][0], outs[1][0])
+    if outs[0][1] is not None:
+        close(outs[1][1].float(), outs[0][1].float(), rtol=1e-5, atol=1e-5, what="column sums")
+
+
 CONVACT = [
     # kind, B, H, Cin(true), Cin padded, Cout(true), n_out, act, bias
     ("k4s2", 2, 16, 3, 4, 16, 16, "lrelu", False),   # first D conv on an NHWC4 image
