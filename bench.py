@@ -388,7 +388,7 @@ def main():
                                                    "weights / Adam"}.get(args.math, "fp32")),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "speech_encoder_in_step": bool(args.with_encoder), "matrix_products": MATH_NOTE[args.math],
-                       "hip_graph": bool(tr._graph is not None and tr._graph.get("graph") is not None)},
+                       "hip_graph": bool(tr._graph is not None and tr._graph.get("graphs") is not None)},
             "step_roofline": {
                 # fractions against the dense MFMA peak of the arithmetic the mode computes in (fp32 157.3; bf16 2500)
                 # what the matrix cores really deliver: multiply-adds of the launched GEMMs (up-blocks at 4 taps per

@@ -56,8 +56,8 @@ extern "C" {
 
 const char* s2i_last_error(void);
 int  s2i_version(void);
-/* Integer tuning knobs of the launch planners (tools and tests; every knob has a measured default).  Returns 0, or
-   non-zero for an unknown key.  The library reads no environment variable on a launch path: the ONE variable
+/* Integer tuning knobs of the launch planners (tools and tests; every knob has a measured default; a negative value
+   restores it, and s2i_get_tuning reports -1 for a knob at its default).  Returns 0, or non-zero for an unknown key.  The library reads no environment variable on a launch path: the ONE variable
    S2I_TUNE="key=value,key=value" is parsed once, when the library is loaded. */
 int  s2i_set_tuning(const char* key, int value);
 int  s2i_get_tuning(const char* key, int* value);

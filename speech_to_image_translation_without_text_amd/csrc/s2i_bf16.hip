@@ -20,9 +20,7 @@
 // Rows of the GEMM are output pixels; a block owns a tile of 128 of them shaped TB x TH x TW (powers of two) chosen
 // from the map size, e.g. 4 x 32 pixels of one image on wide maps, 8 whole 4x4 maps at the discriminators' tails.
 #include "s2i_common.h"
-#include <stdlib.h>
 #include <stdio.h>
-#include <vector>
 
 namespace {
 
@@ -68,12 +66,10 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 
 // KIND: geometry; BN: output channels per block; CK: channels per LDS stage; waves 2x2 (BN >= 64) or 4x1 (BN = 32)
-// TG: taps per LDS stage (T / TG stages per channel chunk); PIN: fragment reads software-pipelined one k-step ahead with the
-// order pinned (sched_barrier) instead of left to the compiler
-// DMA: the weight stage goes global -> LDS directly (global_load_lds, 16 bytes per lane, no VGPRs, no ds_write) into one of
-// TWO stage buffers while the matrix loop reads the other: one barrier per stage instead of two.  The LDS image is the same
-// swizzled [row][CK] image; the swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear).
-template <int KIND, int BN, int CK, int TG, bool PIN, int DBG = 0, bool DMA = false>
+// TG: taps per LDS stage (T / TG stages per channel chunk); fragment reads are software-pipelined one k-step ahead with the
+// order pinned (sched_barrier).  (Measured and removed: compiler-scheduled fragment reads, fewer taps per stage at three
+// blocks per CU, weights by LDS-DMA into two buffers with one barrier per stage -- all within 5 %)
+template <int KIND, int BN, int CK, int TG, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   constexpr int T = KIND == KB_K3S1 ? 9 : (KIND == KB_K4S2 ? 16 : 4);
   constexpr int NG = T / TG;
@@ -91,8 +87,6 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [patch | weight stage], reused by the epilogue
   unsigned char* As = smem;
   unsigned char* Bs = smem + ((p.npix * ROWB + 255) & ~255);
-  constexpr int B_BYTES = TG * BN * ROWB;
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -187,21 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     }
     const int wbase = ((phase * p.nchunk + cc) * NG + tg) * wstage + n0 * CK;
     if ((DBG & 2) && st != s_begin) return;
-    if constexpr (DMA) {
-      unsigned char* dstb = Bs + ((st - s_begin) & 1) * B_BYTES;
-#pragma unroll
-      for (int q = 0; q < NBL; ++q) {
-        if (q * 256 + wave * 64 < BSEG) {            // wave-uniform: a wave-instruction fills 64 consecutive 16-byte slots
-          const int e = tid + q * 256;
-          const int segp = e & (SEGS - 1), row = e / SEGS;          // LDS slot (row, swizzled segment)
-          const int seg = segp ^ ((row >> LGR) & (SEGS - 1));       // ... holds this source segment
-          const int n = row & (BN - 1), t = row / BN;
-          const unsigned short* src = p.w + (wbase + (t * p.Npad + n) * CK + seg * 8);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(dstb + (q * 256 + wave * 64) * 16), 16, 0, 0);
-        }
-      }
-    } else {
+    {
 #pragma unroll
       for (int q = 0; q < NBL; ++q) {
         const int e = tid + q * 256;
@@ -216,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
       for (int q = 0; q < NPL; ++q)
         if (plo[q] >= 0) *reinterpret_cast<u32x4*>(As + plo[q]) = ra[q];
     }
-    if constexpr (!DMA) {
+    {
 #pragma unroll
       for (int q = 0; q < NBL; ++q) {
         const int e = tid + q * 256;
@@ -243,13 +223,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     const int sb = 2 + 6 * min(st - s_begin, 7);
     stamp(sb);
     if (!((DBG & 4) && st != s_begin)) stage(new_a);
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this stage's weights have landed in LDS
     stamp(sb + 1);
     __syncthreads();
     stamp(sb + 2);
     if (st + 1 < s_end) fetch(st + 1, ((st + 1) % NG) == 0);
     const int tg = st % NG;
-    const unsigned char* Bcur = DMA ? Bs + ((st - s_begin) & 1) * B_BYTES : Bs;
+    const unsigned char* Bcur = Bs;
     // LDS byte offsets of this lane's fragments, once per stage: the matrix loop below then spends no vector
     // instructions on addresses (row, swizzle and tap arithmetic per read had the address math competing with the MFMAs
     // for the SIMD's issue slots).  k-step ks of a tap is the ks = 0 offset XOR (ks << 5): the segment index is
@@ -288,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
     };
     constexpr int NS = TG * KS;
     stamp(sb + 3);
-    if constexpr (PIN) {
+    {
       bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
       ldfr(0, a0, b0);
 #pragma unroll
@@ -302,18 +281,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
         if (s2 + 1 < NS) mma(a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
-#pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) {
-        bf16x8 a0[TM], b0[TN];
-        ldfr(s2, a0, b0);
-        mma(a0, b0);
-      }
     }
-    // DMA: the other weight buffer is refilled only after the next leading barrier, so the trailing barrier is needed
-    // only where the (single) patch buffer is about to be overwritten, and before the epilogue reuses LDS
     stamp(sb + 4);
-    if (!DMA || st + 1 >= s_end || ((st + 1) % NG) == 0) __syncthreads();
+    __syncthreads();
     stamp(sb + 5);
   }
 
@@ -1089,7 +1059,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf16_kernel(const float* __
 // ---- host-side planning ------------------------------------------------------------------------------------------
 struct BPlan {
   int v2;   // conv_bf16_v2_kernel: 256-pixel tiles, 512 threads
-  int kb, T, NG, TG, pin, dma, Ho, Wo, nphases, BN, CK, Npad;
+  int kb, T, NG, TG, Ho, Wo, nphases, BN, CK, Npad;
   int lgTW, lgTH, lgTB, tilesX, tilesY, tilesB, PH, PW, npix;
   int nchunk, splitk, cps, gridM, gridN;
   long long Mrows;
@@ -1111,23 +1081,12 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
     case S2I_TCONV_K4S2: pl->kb = KB_TCONV; pl->T = 4; pl->NG = 1; pl->Ho = d->H; pl->Wo = d->W; pl->nphases = 4; break;
     default: S2I_FAIL("conv(bf16): unsupported kind %d", d->kind);
   }
-  // Stage shape.  Default: all 9 taps of a 3x3 / the 4 taps of a transposed-conv phase per stage; the stride-2 4x4 conv
-  // with BN = 128 takes 4 taps x 32 channels (64-byte pieces of a pixel instead of 32-byte ones: measured -10 % time, the
-  // 32-byte pieces left half of every 64-byte memory request unused).  S2I_B16_VARIANT (experiments, tools/conv16_bench.py;
-  // none changed the time by more than 5 %): 1 = a third / quarter / half of the taps per stage (3 blocks per CU),
-  // 2 = the same with compiler-scheduled fragment reads, 3 = weights by LDS-DMA into two buffers, one barrier per stage,
-  // 5 = the round's first shape (8 taps x 16 channels) for the 4x4.
-  static const int variant = getenv("S2I_B16_VARIANT") ? atoi(getenv("S2I_B16_VARIANT")) : 0;
+  // Stage shape: all 9 taps of a 3x3 / the 4 taps of a transposed-conv phase per stage; the stride-2 4x4 conv with BN = 128
+  // takes 4 taps x 32 channels (64-byte pieces of a pixel instead of 32-byte ones: measured -10 % time, the 32-byte pieces
+  // left half of every 64-byte memory request unused).
   pl->BN = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
   pl->TG = pl->kb == KB_K4S2 ? 8 : pl->T;
-  pl->pin = 1;
-  pl->dma = 0;
-  if (variant >= 1 && variant <= 3 && pl->BN == 128) {
-    pl->TG = pl->kb == KB_K3S1 ? 3 : (pl->kb == KB_K4S2 ? 4 : 2);
-    pl->pin = variant != 2;
-    pl->dma = variant == 3;
-  }
-  const bool wide_ck = variant != 5 && !(variant >= 1 && variant <= 3) && pl->BN == 128 && pl->kb == KB_K4S2;
+  const bool wide_ck = pl->BN == 128 && pl->kb == KB_K4S2;
   if (wide_ck) pl->TG = 4;
   pl->NG = pl->T / pl->TG;
   int ck = (pl->kb == KB_TCONV ? 4096 : 2048) / pl->BN;
@@ -1138,11 +1097,11 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
   S2I_REQUIRE((d->Cx % ck) == 0, "conv(bf16): %d channels do not split into chunks of %d", d->Cx, ck);
   pl->CK = ck;
   pl->Npad = s2i_cdiv(d->N, pl->BN) * pl->BN;
-  // second-generation kernel (256-pixel tiles): S2I_B16_V2 = 0 never, 1 (default) where it was measured faster, 2 wherever
-  // it can run
-  const int v2mode = getenv("S2I_B16_V2") ? atoi(getenv("S2I_B16_V2")) : 1;   // read per call: tests switch it
+  // second-generation kernel (256-pixel tiles); tuning knob b16_v2 = 0 never, 1 (default) where it was measured faster, 2
+  // wherever it can run (tests)
+  const int v2mode = s2i_tune(S2I_TUNE_B16_V2, 1);
   pl->v2 = 0;
-  if (v2mode && variant == 0 && pl->BN == 128) {
+  if (v2mode && pl->BN == 128) {
     const int ck2 = pl->kb == KB_TCONV ? 64 : 32;
     int tw2 = pl->Wo < 32 ? pl->Wo : 32, th2 = 256 / tw2;
     if (th2 > pl->Ho) th2 = pl->Ho;
@@ -1226,7 +1185,7 @@ size_t bf16_smem_bytes(const BPlan& pl) {
     const size_t epi2 = (size_t)256 * (128 * 2 + 16);
     return main2 > epi2 ? main2 : epi2;
   }
-  const size_t main_b = ab + (size_t)tg * pl.BN * rowb * (pl.dma ? 2 : 1);
+  const size_t main_b = ab + (size_t)tg * pl.BN * rowb;
   const size_t epi = (size_t)128 * (pl.BN * 2 + 16);
   return main_b > epi ? main_b : epi;
 }
@@ -1237,27 +1196,27 @@ bool bf16_has_kernel(int kb, int bn, int ck) {
   return (bn == 128 && (ck == 16 || ck == 32)) || (bn == 64 && ck == 32) || (bn == 32 && (ck == 64 || ck == 32));
 }
 
-template <int KIND, int BN, int CK, int TG, bool PIN, bool DMA = false>
+template <int KIND, int BN, int CK, int TG>
 int launch_one(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   const size_t shb = bf16_smem_bytes(pl);
   static bool raised = false;  // > 64 KB of dynamic LDS needs the attribute once per kernel
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<KIND, BN, CK, TG, PIN, 0, DMA>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<KIND, BN, CK, TG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) S2I_FAIL("conv(bf16): hipFuncSetAttribute: %s", hipGetErrorString(e));
     raised = true;
   }
-  hipLaunchKernelGGL((conv_bf16_kernel<KIND, BN, CK, TG, PIN, 0, DMA>), grid, dim3(256), shb, st, p);
+  hipLaunchKernelGGL((conv_bf16_kernel<KIND, BN, CK, TG>), grid, dim3(256), shb, st, p);
   return 0;
 }
 
 // blocks along x for the second-generation kernel: persistent (one block per CU looping over its tiles) where the kernel
 // supports it -- single patch buffer, no split-K, and a patch region large enough for the epilogue's transpose
 int v2_grid_x(const BPlan& pl) {
-  const int pers = getenv("S2I_B16_PERSISTENT") ? atoi(getenv("S2I_B16_PERSISTENT")) : 1;
+  const int pers = s2i_tune(S2I_TUNE_B16_PERSIST, 1);
   const size_t ab = ((size_t)pl.npix * (pl.CK * 2 + (v2_padded(pl) ? 16 : 0)) + 255) & ~(size_t)255;
   if (!pers || pl.kb != KB_K4S2 || pl.splitk != 1 || ab < (size_t)256 * (128 * 2 + 16)) return pl.gridM;
-  int nblk = (pers > 1 ? pers : 256) / (pl.gridN * pl.nphases);   // S2I_B16_PERSISTENT > 1: that many block slots (tests)
+  int nblk = (pers > 1 ? pers : 256) / (pl.gridN * pl.nphases);   // knob b16_persist > 1: that many block slots (tests)
   if (nblk < 1) nblk = 1;
   if (pl.gridM <= nblk) return pl.gridM;
   // a block walks ceil(gridM / nblk) tiles: persistent only where that rounding costs little (measured: 144 tiles over
@@ -1282,83 +1241,29 @@ int launch_v2(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+#ifdef S2I_DIAG
+#include "diag/s2i_bf16_diag.inc"
+#endif
+
 int launch_conv_bf16(const BPlan& pl, const ConvBP& p, dim3 grid, hipStream_t st) {
-  const int kb = pl.kb, bn = pl.BN, ck = pl.CK, tg = pl.TG, pin = pl.pin;
-  if (pl.v2 && p.dbg == 32 && kb == KB_K4S2 && p.splitk == 1) {
-    // diagnostic build: stamps into a buffer of its own, written to $S2I_B16_TIMELINE after the launch
-    grid.x = v2_grid_x(pl);
-    const size_t nblk = (size_t)grid.x * grid.y * grid.z, bytes = nblk * 64 * sizeof(unsigned long long);
-    unsigned long long* dbuf = nullptr;
-    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess) S2I_FAIL("conv(bf16): timeline buffer");
-    (void)hipMemsetAsync(dbuf, 0, bytes, st);
-    ConvBP q = p;
-    q.slab = reinterpret_cast<float*>(dbuf);
-    if (v2_padded(pl)) {
-      (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32, 66>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32, 66>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
-    } else {
-      (void)hipFuncSetAttribute((const void*)conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      hipLaunchKernelGGL((conv_bf16_v2_kernel<KB_K4S2, 32, 4, false, 32>), grid, dim3(512), bf16_smem_bytes(pl), st, q);
-    }
-    (void)hipStreamSynchronize(st);
-    const char* path = getenv("S2I_B16_TIMELINE");
-    if (path) {
-      std::vector<unsigned long long> h(nblk * 64);
-      (void)hipMemcpy(h.data(), dbuf, bytes, hipMemcpyDeviceToHost);
-      FILE* f = fopen(path, "wb");
-      if (f) { fwrite(h.data(), 1, bytes, f); fclose(f); }
-    }
-    (void)hipFree(dbuf);
-    return 0;
+  const int kb = pl.kb, bn = pl.BN, ck = pl.CK, tg = pl.TG;
+#ifdef S2I_DIAG
+  {   // libs2i_hip_diag.so only (make diag): ablation / in-kernel timeline instantiations of tools/conv16_*.py
+    int rc = 0;
+    if (diag_launch_conv_bf16(pl, p, grid, st, &rc)) return rc;
   }
+#endif
   if (pl.v2) {
     if (kb == KB_K4S2 && v2_padded(pl)) return launch_v2<KB_K4S2, 32, 4, false, 66>(pl, p, grid, st);
     if (kb == KB_K4S2) return launch_v2<KB_K4S2, 32, 4, false>(pl, p, grid, st);
     if (kb == KB_K3S1) return launch_v2<KB_K3S1, 32, 3, true>(pl, p, grid, st);
     return launch_v2<KB_TCONV, 64, 2, true>(pl, p, grid, st);
   }
-  if (pl.dma) {
-    if (kb == KB_K3S1 && bn == 128 && ck == 16 && tg == 3) return launch_one<KB_K3S1, 128, 16, 3, true, true>(pl, p, grid, st);
-    if (kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 4) return launch_one<KB_K4S2, 128, 16, 4, true, true>(pl, p, grid, st);
-    if (kb == KB_TCONV && bn == 128 && ck == 32 && tg == 2) return launch_one<KB_TCONV, 128, 32, 2, true, true>(pl, p, grid, st);
-    S2I_FAIL("conv(bf16): no DMA kernel for kind %d BN=%d CK=%d TG=%d", kb, bn, ck, tg);
-  }
-#define S2I_CASE(K, bn_, ck_, tg_, pin_) \
-  if (kb == K && bn == bn_ && ck == ck_ && tg == tg_ && pin == pin_) return launch_one<K, bn_, ck_, tg_, pin_>(pl, p, grid, st);
-  if (p.dbg && kb == KB_K4S2 && bn == 128 && ck == 16 && tg == 8 && pin) {
-    const size_t shb = bf16_smem_bytes(pl);
-#define S2I_DBG(v) if (p.dbg == v) { (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 16, 8, true, v>), grid, dim3(256), shb, st, p); return 0; }
-    S2I_DBG(1) S2I_DBG(2) S2I_DBG(4) S2I_DBG(7) S2I_DBG(8) S2I_DBG(15) S2I_DBG(16) S2I_DBG(31) S2I_DBG(24)
-#undef S2I_DBG
-  }
-  if (p.dbg == 32 && kb == KB_K4S2 && bn == 128 && ck == 32 && tg == 4 && pin && p.splitk == 1) {
-    // diagnostic build: stamps into a buffer of its own, written to $S2I_B16_TIMELINE after the launch
-    const size_t nblk = (size_t)grid.x * grid.y * grid.z, bytes = nblk * 64 * sizeof(unsigned long long);
-    unsigned long long* dbuf = nullptr;
-    if (hipMalloc((void**)&dbuf, bytes) != hipSuccess) S2I_FAIL("conv(bf16): timeline buffer");
-    (void)hipMemsetAsync(dbuf, 0, bytes, st);
-    ConvBP q = p;
-    q.slab = reinterpret_cast<float*>(dbuf);
-    (void)hipFuncSetAttribute((const void*)conv_bf16_kernel<KB_K4S2, 128, 32, 4, true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    hipLaunchKernelGGL((conv_bf16_kernel<KB_K4S2, 128, 32, 4, true, 32>), grid, dim3(256), bf16_smem_bytes(pl), st, q);
-    (void)hipStreamSynchronize(st);
-    const char* path = getenv("S2I_B16_TIMELINE");
-    if (path) {
-      std::vector<unsigned long long> h(nblk * 64);
-      (void)hipMemcpy(h.data(), dbuf, bytes, hipMemcpyDeviceToHost);
-      FILE* f = fopen(path, "wb");
-      if (f) { fwrite(h.data(), 1, bytes, f); fclose(f); }
-    }
-    (void)hipFree(dbuf);
-    return 0;
-  }
-  S2I_CASE(KB_K3S1, 128, 32, 3, true) S2I_CASE(KB_K4S2, 128, 32, 4, true)
-  S2I_CASE(KB_K3S1, 128, 16, 9, true) S2I_CASE(KB_K3S1, 128, 16, 3, true) S2I_CASE(KB_K3S1, 128, 16, 3, false)
-  S2I_CASE(KB_K3S1, 64, 32, 9, true) S2I_CASE(KB_K3S1, 32, 64, 9, true) S2I_CASE(KB_K3S1, 32, 32, 9, true)
-  S2I_CASE(KB_K4S2, 128, 16, 8, true) S2I_CASE(KB_K4S2, 128, 16, 4, true) S2I_CASE(KB_K4S2, 128, 16, 4, false)
-  S2I_CASE(KB_K4S2, 64, 32, 8, true) S2I_CASE(KB_K4S2, 32, 32, 8, true)
-  S2I_CASE(KB_TCONV, 128, 32, 4, true) S2I_CASE(KB_TCONV, 128, 32, 2, true) S2I_CASE(KB_TCONV, 128, 32, 2, false)
-  S2I_CASE(KB_TCONV, 64, 64, 4, true) S2I_CASE(KB_TCONV, 32, 64, 4, true) S2I_CASE(KB_TCONV, 32, 32, 4, true)
+#define S2I_CASE(K, bn_, ck_, tg_) \
+  if (kb == K && bn == bn_ && ck == ck_ && tg == tg_) return launch_one<K, bn_, ck_, tg_>(pl, p, grid, st);
+  S2I_CASE(KB_K3S1, 128, 16, 9) S2I_CASE(KB_K3S1, 64, 32, 9) S2I_CASE(KB_K3S1, 32, 64, 9) S2I_CASE(KB_K3S1, 32, 32, 9)
+  S2I_CASE(KB_K4S2, 128, 32, 4) S2I_CASE(KB_K4S2, 128, 16, 8) S2I_CASE(KB_K4S2, 64, 32, 8) S2I_CASE(KB_K4S2, 32, 32, 8)
+  S2I_CASE(KB_TCONV, 128, 32, 4) S2I_CASE(KB_TCONV, 64, 64, 4) S2I_CASE(KB_TCONV, 32, 64, 4) S2I_CASE(KB_TCONV, 32, 32, 4)
 #undef S2I_CASE
   S2I_FAIL("conv(bf16): no kernel for kind %d BN=%d CK=%d TG=%d", kb, bn, ck, tg);
 }
@@ -1461,8 +1366,11 @@ extern "C" int s2i_conv_forward_bf16(const s2i_conv_desc* d, const unsigned shor
   const unsigned long long wb = (unsigned long long)pl.nphases * pl.T * pl.Npad * d->Cx * 2ull;
   S2I_REQUIRE(xb < 0x7ff00000ull && wb < 0x7ff00000ull, "conv(bf16): tensor exceeds the 2 GiB buffer-addressing window");
   p.x_bytes = (unsigned)xb; p.w_bytes = (unsigned)wb;
-  static const int dbg = getenv("S2I_B16_DBG") ? atoi(getenv("S2I_B16_DBG")) : 0;
-  p.dbg = dbg;
+#ifdef S2I_DIAG
+  p.dbg = s2i_tune(S2I_TUNE_B16_DBG, 0);
+#else
+  p.dbg = 0;
+#endif
   dim3 grid(pl.gridM, pl.gridN, pl.nphases * pl.splitk);
   if (launch_conv_bf16(pl, p, grid, ST)) return 1;
   S2I_LAUNCH_CHECK("conv_bf16");

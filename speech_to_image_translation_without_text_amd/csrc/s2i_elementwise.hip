@@ -1185,7 +1185,7 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long
 // sigmoid).  These kernels fix a thread to V channels (8 for bf16: 16-byte loads; 4 for fp32) and let it walk rows: every
 // coefficient lives in registers, there is no division, two rows' loads are issued before the first is used, and a GLU pair
 // (value channel c, gate channel C/2 + c) is ONE thread's work.
-#define S2I_EW_ROWS_DEFAULT 1   // measured: the forward form wins for bf16 tensors; the backward forms lose to the walkers above
+// Row-tiled FORWARD kernel for bf16 tensors (measured: wins there; row-tiled backward forms lost to the walkers above and were removed).
 typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
 template <int V> struct fv { f32x4 v[V / 4]; };
 
@@ -1289,209 +1289,6 @@ __global__ __launch_bounds__(256) void bn_act_fwd_rows_kernel(const T* __restric
     if (two) x0 = ldv<V>(second + row * ld2 + c0);
     one(row, a0, x0);
   }
-}
-
-// per-half coefficient registers of the backward passes
-template <int V> struct BnCo { fv<V> s, t, mean, istd; };
-template <int V> __device__ __forceinline__ BnCo<V> bn_co(const float* coef, int C, int c0) {
-  BnCo<V> c;
-  c.mean = ldv<V>(coef + c0); c.istd = ldv<V>(coef + C + c0); c.s = ldv<V>(coef + 2 * C + c0); c.t = ldv<V>(coef + 3 * C + c0);
-  return c;
-}
-
-// dz of one row for this thread's channels.  GLU: (value half a, gate half g) -> (dz_a, dz_g); otherwise dz_a only.
-template <typename T, int V>
-__device__ __forceinline__ void row_dz(int act, const BnCo<V>& ca, const BnCo<V>& cg, const fv<V>& ya, const fv<V>& yg,
-                                       const fv<V>& d, fv<V>& dza, fv<V>& dzg) {
-#pragma unroll
-  for (int k = 0; k < V / 4; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float za = ca.s.v[k][j] * ya.v[k][j] + ca.t.v[k][j];
-      if (act == S2I_ACT_GLU) {
-        const float sgm = sigmoid_gate_<T>(cg.s.v[k][j] * yg.v[k][j] + cg.t.v[k][j]);
-        dza.v[k][j] = d.v[k][j] * sgm;
-        dzg.v[k][j] = d.v[k][j] * za * sgm * (1.f - sgm);
-      } else if (act == S2I_ACT_LRELU) {
-        dza.v[k][j] = za > 0.f ? d.v[k][j] : 0.2f * d.v[k][j];
-      } else {
-        dza.v[k][j] = d.v[k][j];
-      }
-    }
-}
-
-template <typename T, int V, int ACT = -1>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
-                                                                    int lddout, long long M, int C,
-                                                                    const float* __restrict__ coef0,
-                                                                    const float* __restrict__ red20, int act_rt,
-                                                                    T* __restrict__ dy, int lgc, int ppg, long long Rg) {
-  const int act = ACT >= 0 ? ACT : act_rt;
-  const int cpb = 1 << lgc, rpb = 256 >> lgc;
-  const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
-  const bool glu = act == S2I_ACT_GLU;
-  const int Ch = glu ? C / 2 : C;                       // channels the threads are spread over
-  const int c0 = (blockIdx.y * cpb + ql) * V;
-  if (c0 >= Ch) return;
-  const RowSpan sp = row_span(M, ppg, Rg);
-  const float* coef = coef0 + (size_t)sp.grp * 4 * C;
-  const float* red2 = red20 + (size_t)sp.grp * 2 * C;
-  const BnCo<V> ca = bn_co<V>(coef, C, c0);
-  BnCo<V> cg = ca;
-  const fv<V> m0a = ldv<V>(red2 + c0), m1a = ldv<V>(red2 + C + c0);
-  fv<V> m0g = m0a, m1g = m1a;
-  if (glu) { cg = bn_co<V>(coef, C, Ch + c0); m0g = ldv<V>(red2 + Ch + c0); m1g = ldv<V>(red2 + C + Ch + c0); }
-  auto one = [&](long long row, const fv<V>& ya, const fv<V>& yg, const fv<V>& d) {
-    fv<V> dza, dzg, oa, og;
-    row_dz<T, V>(act, ca, cg, ya, yg, d, dza, dzg);
-#pragma unroll
-    for (int k = 0; k < V / 4; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xa = (ya.v[k][j] - ca.mean.v[k][j]) * ca.istd.v[k][j];
-        oa.v[k][j] = ca.s.v[k][j] * (dza.v[k][j] - m0a.v[k][j] - xa * m1a.v[k][j]);
-        if (glu) {
-          const float xg = (yg.v[k][j] - cg.mean.v[k][j]) * cg.istd.v[k][j];
-          og.v[k][j] = cg.s.v[k][j] * (dzg.v[k][j] - m0g.v[k][j] - xg * m1g.v[k][j]);
-        }
-      }
-    stv<V>(dy + row * C + c0, oa);
-    if (glu) stv<V>(dy + row * C + Ch + c0, og);
-  };
-  long long row = sp.r0 + rl;
-  for (; row + rpb < sp.r1; row += 2 * rpb) {
-    const fv<V> a0 = ldv<V>(y + row * C + c0), a1 = ldv<V>(y + (row + rpb) * C + c0);
-    const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
-    fv<V> g0 = a0, g1 = a1;
-    if (glu) { g0 = ldv<V>(y + row * C + Ch + c0); g1 = ldv<V>(y + (row + rpb) * C + Ch + c0); }
-    one(row, a0, g0, d0);
-    one(row + rpb, a1, g1, d1);
-  }
-  if (row < sp.r1) {
-    const fv<V> a0 = ldv<V>(y + row * C + c0), d0 = ldv<V>(dout + row * lddout + c0);
-    fv<V> g0 = a0;
-    if (glu) g0 = ldv<V>(y + row * C + Ch + c0);
-    one(row, a0, g0, d0);
-  }
-}
-
-// column sums of (dz, dz * xhat) over this block's rows: part[0 / 1][blockIdx.x][C], as colreduce_kernel<1>
-template <typename T, int V, int ACT = -1>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce_rows_kernel(const T* __restrict__ y, const T* __restrict__ dout,
-                                                                     int lddout, long long M, int C,
-                                                                     const float* __restrict__ coef0, int act_rt,
-                                                                     float* __restrict__ part, int nparts, int lgc, int ppg,
-                                                                     long long Rg) {
-  const int act = ACT >= 0 ? ACT : act_rt;
-  constexpr int NQ = V / 4;
-  __shared__ f32x4 sh[4 * NQ][256];                     // [sum index][thread]
-  const int cpb = 1 << lgc, rpb = 256 >> lgc;
-  const int tid = threadIdx.x, ql = tid & (cpb - 1), rl = tid >> lgc;
-  const bool glu = act == S2I_ACT_GLU;
-  const int Ch = glu ? C / 2 : C;
-  const int c0 = (blockIdx.y * cpb + ql) * V;
-  const bool live = c0 < Ch;
-  const RowSpan sp = row_span(M, ppg, Rg);
-  fv<V> s0a, s1a, s0g, s1g;
-#pragma unroll
-  for (int k = 0; k < NQ; ++k) s0a.v[k] = s1a.v[k] = s0g.v[k] = s1g.v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    const float* coef = coef0 + (size_t)sp.grp * 4 * C;
-    const BnCo<V> ca = bn_co<V>(coef, C, c0);
-    BnCo<V> cg = ca;
-    if (glu) cg = bn_co<V>(coef, C, Ch + c0);
-    auto one = [&](const fv<V>& ya, const fv<V>& yg, const fv<V>& d) {
-      fv<V> dza, dzg;
-      row_dz<T, V>(act, ca, cg, ya, yg, d, dza, dzg);
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        s0a.v[k] += dza.v[k];
-        s1a.v[k] += dza.v[k] * ((ya.v[k] - ca.mean.v[k]) * ca.istd.v[k]);
-        if (glu) {
-          s0g.v[k] += dzg.v[k];
-          s1g.v[k] += dzg.v[k] * ((yg.v[k] - cg.mean.v[k]) * cg.istd.v[k]);
-        }
-      }
-    };
-    long long row = sp.r0 + rl;
-    for (; row + rpb < sp.r1; row += 2 * rpb) {
-      const fv<V> a0 = ldv<V>(y + row * C + c0), a1 = ldv<V>(y + (row + rpb) * C + c0);
-      const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
-      fv<V> g0 = a0, g1 = a1;
-      if (glu) { g0 = ldv<V>(y + row * C + Ch + c0); g1 = ldv<V>(y + (row + rpb) * C + Ch + c0); }
-      one(a0, g0, d0);
-      one(a1, g1, d1);
-    }
-    if (row < sp.r1) {
-      const fv<V> a0 = ldv<V>(y + row * C + c0), d0 = ldv<V>(dout + row * lddout + c0);
-      fv<V> g0 = a0;
-      if (glu) g0 = ldv<V>(y + row * C + Ch + c0);
-      one(a0, g0, d0);
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NQ; ++k) {
-    sh[0 * NQ + k][tid] = s0a.v[k];
-    sh[1 * NQ + k][tid] = s1a.v[k];
-    sh[2 * NQ + k][tid] = s0g.v[k];
-    sh[3 * NQ + k][tid] = s1g.v[k];
-  }
-  __syncthreads();
-  if (rl == 0 && live) {
-    for (int r = 1; r < rpb; ++r)
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        s0a.v[k] += sh[0 * NQ + k][r * cpb + ql];
-        s1a.v[k] += sh[1 * NQ + k][r * cpb + ql];
-        if (glu) {
-          s0g.v[k] += sh[2 * NQ + k][r * cpb + ql];
-          s1g.v[k] += sh[3 * NQ + k][r * cpb + ql];
-        }
-      }
-    float* p0 = part + ((size_t)0 * nparts + blockIdx.x) * C;
-    float* p1 = part + ((size_t)1 * nparts + blockIdx.x) * C;
-    stv<V>(p0 + c0, s0a);
-    stv<V>(p1 + c0, s1a);
-    if (glu) { stv<V>(p0 + Ch + c0, s0g); stv<V>(p1 + Ch + c0, s1g); }
-  }
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void act_bwd_rows_kernel(const T* __restrict__ out, const T* __restrict__ dout,
-                                                           int lddout, long long M, int C, int act, T* __restrict__ dy,
-                                                           int lgc, int ppg) {
-  const int cpb = 1 << lgc, rpb = 256 >> lgc;
-  const int ql = threadIdx.x & (cpb - 1), rl = threadIdx.x >> lgc;
-  const int c0 = (blockIdx.y * cpb + ql) * V;
-  if (c0 >= C) return;
-  const RowSpan sp = row_span(M, ppg, M);
-  auto one = [&](long long row, const fv<V>& ov, const fv<V>& d) {
-    fv<V> o;
-#pragma unroll
-    for (int k = 0; k < V / 4; ++k)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (act == S2I_ACT_LRELU) o.v[k][j] = ov.v[k][j] > 0.f ? d.v[k][j] : 0.2f * d.v[k][j];
-        else if (act == S2I_ACT_TANH) o.v[k][j] = d.v[k][j] * (1.f - ov.v[k][j] * ov.v[k][j]);
-        else o.v[k][j] = d.v[k][j];
-      }
-    stv<V>(dy + row * C + c0, o);
-  };
-  long long row = sp.r0 + rl;
-  for (; row + rpb < sp.r1; row += 2 * rpb) {
-    const fv<V> o0 = ldv<V>(out + row * C + c0), o1 = ldv<V>(out + (row + rpb) * C + c0);
-    const fv<V> d0 = ldv<V>(dout + row * lddout + c0), d1 = ldv<V>(dout + (row + rpb) * lddout + c0);
-    one(row, o0, d0);
-    one(row + rpb, o1, d1);
-  }
-  if (row < sp.r1) one(row, ldv<V>(out + row * C + c0), ldv<V>(dout + row * lddout + c0));
-}
-
-// S2I_EW_ROWS: which passes take the row-tiled kernels (bit 0 forward, 1 backward reduce, 2 backward apply, 3 plain
-// activation backward); read per call (tools/elementwise_bench.py switches it)
-static int ew_rows_mask() {
-  const char* e = getenv("S2I_EW_ROWS");
-  return e ? atoi(e) : S2I_EW_ROWS_DEFAULT;
 }
 
 // host geometry of the row-tiled kernels: threads across the channel vectors (a power of two), the rest of the block
@@ -1616,8 +1413,7 @@ static int bn_act_forward_impl(const T* y, long long M, int groups, int C, const
   S2I_REQUIRE(!(residual && act == S2I_ACT_GLU), "bn_act_forward: residual with GLU unsupported");
   const int Cout = act == S2I_ACT_GLU ? C / 2 : C;
   constexpr bool is16 = sizeof(T) == 2;
-  const bool rows_on = (ew_rows_mask() & 1) != 0 && (is16 || (ew_rows_mask() & 16) != 0);   // fp32: no gain (bit 4 forces it)
-  if (rows_on) {
+  if (is16) {   // fp32 tensors: no gain from the row-tiled form
 #define S2I_FWDR(VV, ACTV) hipLaunchKernelGGL((bn_act_fwd_rows_kernel<T, VV, ACTV>), dim3(groups * g.ppg, g.gy), dim3(256), 0, ST, \
                                               y, M, C, coef4, act, residual, out, g.lgc, g.ppg, M / groups)
     if (is16 && (Cout % 8) == 0) {
@@ -1664,29 +1460,9 @@ static int bn_act_bwd_reduce_impl(const T* y, const T* dout, int lddout, long lo
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && nparts % groups == 0, "bn_act_bwd_reduce: bad grouping");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_reduce: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_reduce: lddout alignment");
-  const bool rows_on = (ew_rows_mask() & 2) != 0;
-  if (rows_on) {
-    const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
-#define S2I_REDR(VV, ACTV) hipLaunchKernelGGL((bn_act_bwd_reduce_rows_kernel<T, VV, ACTV>), dim3(nparts, g.gy), dim3(256), 0, ST, y, \
-                                              dout, lddout, M, C, coef4, act, part, nparts, g.lgc, g.ppg, M / groups)
-    if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
-      const RowGeom g = row_geom(Ch / 8, M / groups, groups, nparts / groups);
-      if (act == S2I_ACT_GLU) S2I_REDR(8, S2I_ACT_GLU);
-      else if (act == S2I_ACT_LRELU) S2I_REDR(8, S2I_ACT_LRELU);
-      else S2I_REDR(8, -1);
-    } else {
-      const RowGeom g = row_geom(Ch / 4, M / groups, groups, nparts / groups);
-      if (act == S2I_ACT_GLU) S2I_REDR(4, S2I_ACT_GLU);
-      else if (act == S2I_ACT_LRELU) S2I_REDR(4, S2I_ACT_LRELU);
-      else S2I_REDR(4, -1);
-    }
-#undef S2I_REDR
-    S2I_LAUNCH_CHECK("bn_act_bwd_reduce(rows)");
-    return 0;
-  }
   RedGeom g = red_geom(C);
-  // the activation as a template constant (S2I_EW_SPEC=0: the runtime form, for comparison): see colreduce_kernel
-  const bool spec = !(getenv("S2I_EW_SPEC") && atoi(getenv("S2I_EW_SPEC")) == 0);
+  // the activation as a template constant: see colreduce_kernel
+  const bool spec = true;
 #define S2I_RED(ACTV) hipLaunchKernelGGL((colreduce_kernel<1, T, ACTV, 4>), dim3(nparts, g.gy), dim3(256), 0, ST, y, C, \
                                          dout, lddout, M, C, coef4, act, part, nparts, g.cpb, nparts / groups, M / groups)
   if (spec && act == S2I_ACT_LRELU) S2I_RED(S2I_ACT_LRELU);
@@ -1722,28 +1498,7 @@ static int bn_act_bwd_apply_impl(const T* y, const T* dout, int lddout, long lon
   S2I_REQUIRE(groups >= 1 && M % groups == 0 && M < (1ll << 31), "bn_act_bwd_apply: rows do not split into groups");
   S2I_REQUIRE(act == S2I_ACT_GLU ? C % 8 == 0 : C % 4 == 0, "bn_act_bwd_apply: C alignment");
   S2I_REQUIRE(lddout % 4 == 0, "bn_act_bwd_apply: lddout alignment");
-  const bool rows_on = (ew_rows_mask() & 4) != 0;
-  if (rows_on) {
-    const int Ch = act == S2I_ACT_GLU ? C / 2 : C;
-#define S2I_APPR(VV, ACTV) hipLaunchKernelGGL((bn_act_bwd_apply_rows_kernel<T, VV, ACTV>), dim3(groups * g.ppg, g.gy), dim3(256), 0, \
-                                              ST, y, dout, lddout, M, C, coef4, red2, act, dy, g.lgc, g.ppg, M / groups)
-    if (sizeof(T) == 2 && (Ch % 8) == 0 && (lddout % 8) == 0) {
-      const RowGeom g = row_geom(Ch / 8, M / groups, groups, 0);
-      if (act == S2I_ACT_GLU) S2I_APPR(8, S2I_ACT_GLU);
-      else if (act == S2I_ACT_LRELU) S2I_APPR(8, S2I_ACT_LRELU);
-      else S2I_APPR(8, -1);
-    } else {
-      const RowGeom g = row_geom(Ch / 4, M / groups, groups, 0);
-      if (act == S2I_ACT_GLU) S2I_APPR(4, S2I_ACT_GLU);
-      else if (act == S2I_ACT_LRELU) S2I_APPR(4, S2I_ACT_LRELU);
-      else S2I_APPR(4, -1);
-    }
-#undef S2I_APPR
-    S2I_LAUNCH_CHECK("bn_act_bwd_apply(rows)");
-    return 0;
-  }
-  if (!(getenv("S2I_EW_WALK") && atoi(getenv("S2I_EW_WALK")) == 0) &&
-      (act == S2I_ACT_GLU || act == S2I_ACT_LRELU || act == S2I_ACT_NONE)) {
+  if (act == S2I_ACT_GLU || act == S2I_ACT_LRELU || act == S2I_ACT_NONE) {
     RedGeom g = red_geom(C);
     const long long Rg = M / groups;
     const int rpb = 256 / g.cpb;
@@ -1782,20 +1537,6 @@ extern "C" int s2i_bn_act_bwd_apply_dt(int dtype, const void* y, const void* dou
 template <typename T>
 static int act_backward_impl(const T* out, const T* dout, int lddout, long long M, int C, int act, T* dy, void* stream) {
   S2I_REQUIRE(out && dout && dy && M > 0 && C > 0 && C % 4 == 0 && lddout % 4 == 0, "act_backward: bad args");
-  const bool rows_on = (ew_rows_mask() & 8) != 0;
-  if (rows_on) {
-    if (sizeof(T) == 2 && (C % 8) == 0 && (lddout % 8) == 0) {
-      const RowGeom g = row_geom(C / 8, M, 1, 0);
-      hipLaunchKernelGGL((act_bwd_rows_kernel<T, 8>), dim3(g.ppg, g.gy), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy,
-                         g.lgc, g.ppg);
-    } else {
-      const RowGeom g = row_geom(C / 4, M, 1, 0);
-      hipLaunchKernelGGL((act_bwd_rows_kernel<T, 4>), dim3(g.ppg, g.gy), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy,
-                         g.lgc, g.ppg);
-    }
-    S2I_LAUNCH_CHECK("act_backward(rows)");
-    return 0;
-  }
   if (act == S2I_ACT_LRELU)
     hipLaunchKernelGGL((act_bwd_kernel<T, S2I_ACT_LRELU>), dim3(grid_for(M * (C / 4))), dim3(256), 0, ST, out, dout, lddout, M, C, act, dy);
   else if (act == S2I_ACT_TANH)

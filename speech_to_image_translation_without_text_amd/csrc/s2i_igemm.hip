@@ -18,7 +18,6 @@
 // (ds_read_b32, conflict-free).  Global->LDS staging goes through registers with the next chunk's
 // loads in flight during the MFMA loop.
 #include "s2i_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -2358,8 +2357,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
   S2I_REQUIRE(!wsp || pl.bm == 128, "conv(split): the split-bf16 kernels have 128-row tiles (set tile_rows = 128)");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
-  static const bool rgb_on = !(getenv("S2I_RGB") && atoi(getenv("S2I_RGB")) == 0);
-  const int rk = (!wsp && !cls_bias && rgb_on) ? rgb_kind(d, pl, x16, y16) : 0;
+  const int rk = (!wsp && !cls_bias) ? rgb_kind(d, pl, x16, y16) : 0;
   if (rk && ws && ws_bytes >= rgb_afrag_elems(d, pl, rk) * 2 && !(rk == 2 && bias)) {
     unsigned short* afrag = (unsigned short*)ws;
     const int total = (int)rgb_afrag_elems(d, pl, rk);
@@ -2389,8 +2387,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     S2I_LAUNCH_CHECK("rgb_conv");
     return 0;
   }
-  static const bool thin_on = !(getenv("S2I_THIN") && atoi(getenv("S2I_THIN")) == 0);
-  const int tk = (!wsp && !cls_bias && thin_on) ? thin_kind(d, pl) : 0;
+  const int tk = (!wsp && !cls_bias) ? thin_kind(d, pl) : 0;
   if (tk && ws && ws_bytes >= thin_table_floats(d, pl, tk) * sizeof(float)) {
     p.wt = d->wmode != 0;
     float* table = (float*)ws;
@@ -2554,8 +2551,7 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     p.c_bytes = (unsigned)((unsigned long long)d->B * d->Cc * 4ull);
   }
   dim3 grid(pl.gridK, pl.gridN, pl.splitk);
-  static const bool a32_on = !(getenv("S2I_WGRAD_A32") && atoi(getenv("S2I_WGRAD_A32")) == 0);
-  if (a32_on && !a16 && g16 && d->kind == S2I_CONV_K4S2 && d->Ca == 4 && d->Cc == 0 && pl.K == 64 && d->N <= 64 && (d->N % 8) == 0 &&
+  if (!a16 && g16 && d->kind == S2I_CONV_K4S2 && d->Ca == 4 && d->Cc == 0 && pl.K == 64 && d->N <= 64 && (d->N % 8) == 0 &&
       (d->ldg % 8) == 0) {
     // first discriminator conv: fp32 NHWC4 image x bf16 output gradient on the bf16 matrix cores
     WgradP q = p;

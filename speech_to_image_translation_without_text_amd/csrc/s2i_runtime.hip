@@ -29,7 +29,7 @@ extern "C" int s2i_check_device(void) {
 
 // ---- tuning knobs ----------------------------------------------------------------------------------------------------
 #include <stdlib.h>
-static const char* const g_tune_names[S2I_TUNE_COUNT] = {"fwd_bm", "fwd_min_cps", "b16_v2", "b16_persist"};
+static const char* const g_tune_names[S2I_TUNE_COUNT] = {"fwd_bm", "fwd_min_cps", "b16_v2", "b16_persist", "b16_dbg"};
 static int g_tune_val[S2I_TUNE_COUNT];
 static bool g_tune_set[S2I_TUNE_COUNT];
 
@@ -62,7 +62,7 @@ extern "C" int s2i_set_tuning(const char* key, int value) {
   const int i = key ? tune_index(key, strlen(key)) : -1;
   if (i < 0) S2I_FAIL("set_tuning: unknown key '%s'", key ? key : "(null)");
   g_tune_val[i] = value;
-  g_tune_set[i] = true;
+  g_tune_set[i] = value >= 0;      // knobs are non-negative; a negative value restores the built-in default
   return 0;
 }
 

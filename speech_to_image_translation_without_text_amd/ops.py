@@ -39,53 +39,23 @@ def _direct(p):
 
 
 class param_grad_mode:
-    """Scope of the two module-level switches: `with param_grad_mode(direct=True): ...` turns the direct
-    accumulation into `.grad` (and, optionally, the companion weight-gradient streams) on for the body and restores
-    the previous values afterwards, so a later stock-optimiser use of the same modules in this process sees the
-    default (autograd-returned gradients)."""
+    """Scope of the module-level switch: `with param_grad_mode(direct=True): ...` turns the direct accumulation into
+    `.grad` on for the body and restores the previous value afterwards, so a later stock-optimiser use of the same
+    modules in this process sees the default (autograd-returned gradients)."""
 
-    def __init__(self, direct=True, wgrad_side_stream=False):
-        self.new = (bool(direct), bool(wgrad_side_stream))
+    def __init__(self, direct=True):
+        self.new = bool(direct)
 
     def __enter__(self):
-        global DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM
-        self.old = (DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM)
-        DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM = self.new
+        global DIRECT_PARAM_GRAD
+        self.old = DIRECT_PARAM_GRAD
+        DIRECT_PARAM_GRAD = self.new
         return self
 
     def __exit__(self, *exc):
-        global DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM
-        DIRECT_PARAM_GRAD, WGRAD_SIDE_STREAM = self.old
+        global DIRECT_PARAM_GRAD
+        DIRECT_PARAM_GRAD = self.old
         return False
-
-
-# In direct mode the weight-gradient GEMMs are off the backward critical path (nothing downstream reads them
-# until the optimiser): when WGRAD_SIDE_STREAM is on they are launched on a companion HIP stream of the stream
-# the backward runs on, so they fill the CUs left idle by the short BatchNorm / reduction kernels of the
-# input-gradient chain.  `join_wgrad_streams()` must run before the gradients are consumed.
-WGRAD_SIDE_STREAM = False
-_wgrad_streams = {}
-_wgrad_keep = {}     # backward stream -> operands of the weight-gradient launches still in flight on its companion stream
-
-
-def _wgrad_stream():
-    cur = torch.cuda.current_stream()
-    side = _wgrad_streams.get(cur.cuda_stream)
-    if side is None:
-        side = torch.cuda.Stream()
-        _wgrad_streams[cur.cuda_stream] = side
-    return cur, side
-
-
-def join_wgrad_streams():
-    """Make the current stream wait for every companion weight-gradient stream."""
-    if not _wgrad_streams:
-        return
-    cur = torch.cuda.current_stream()
-    side = _wgrad_streams.get(cur.cuda_stream)
-    if side is not None:
-        cur.wait_stream(side)
-    _wgrad_keep.pop(cur.cuda_stream, None)
 
 
 def _lib_ready():
@@ -97,16 +67,21 @@ def _lib_ready():
 # ---- scratch ------------------------------------------------------------------------------------
 class _Workspace:
     """One growable scratch buffer per (device, stream): kernels on a stream use it one after another, and two
-    streams never share one."""
+    streams never share one.  Once a hipGraph has been captured (`pin_graph_resources`) a buffer that has to grow is
+    replaced but never freed: the graph keeps writing split-K slabs through the raw pointer it captured."""
 
     def __init__(self):
         self.buf = {}
+        self.pinned = False
+        self.retired = []
 
     def get(self, nbytes, device):
         nbytes = max(int(nbytes), 16)
         key = (device, stream())     # the raw query: a Stream object per scratch request cost 8 us (tools/host_profile.py)
         cur = self.buf.get(key)
         if cur is None or cur.numel() * 4 < nbytes:
+            if cur is not None and self.pinned:
+                self.retired.append(cur)
             # during hipGraph capture the allocation comes from the graph's private pool and stays reserved for it
             cur = torch.empty((nbytes + 3) // 4 + 1024, dtype=torch.float32, device=device)
             self.buf[key] = cur
@@ -114,6 +89,24 @@ class _Workspace:
 
 
 _ws = _Workspace()
+
+
+def pin_graph_resources():
+    """Called before a hipGraph capture: everything a captured launch reaches through a raw pointer that lives outside
+    the graph's own memory pool -- the per-stream workspaces, the device tables of the batched weight packs -- is kept
+    alive for the rest of the process (replaced workspaces are retired, not freed; the table caches are no longer cleared)."""
+    _ws.pinned = True
+
+
+def invalidate_derived(params):
+    """Drop every weight copy derived from the packed fp32 tensors of these parameters (bf16 stage layouts, split bf16
+    planes): they are re-derived from the current packed weights on first use.  Needed before an eager step that follows
+    hipGraph replays, which update the masters and re-pack on the device without running the host-side bookkeeping."""
+    for p in params:
+        packs = getattr(p, '_s2i_packs', None)
+        if packs:
+            for ent in packs.values():
+                ent[0]._s2i_gen = getattr(ent[0], '_s2i_gen', 0) + 1
 
 
 def _roundup4(v):
@@ -175,7 +168,7 @@ def refresh_packed(params):
             max_taps = max(max_taps, KH * KW)
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(entries[0][0].device)
         tab = (key, raw, len(entries), block0, max_taps)
-        if len(_pack_tables) > 64:
+        if len(_pack_tables) > 64 and not _ws.pinned:   # a captured graph reads its table through a raw pointer
             _pack_tables.clear()
         _pack_tables[key] = tab
     check(lib.s2i_pack_conv_weights_batched(ptr(tab[1]), tab[2], tab[3], tab[4], stream()), "s2i_pack_conv_weights_batched")
@@ -214,7 +207,7 @@ def _refresh_bf16(packed_list):
             block0 += nb
         raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).to(recs[0][0].device)
         tab = (raw, len(recs), block0)
-        if len(_pack16_tables) > 64:
+        if len(_pack16_tables) > 64 and not _ws.pinned:
             _pack16_tables.clear()
         _pack16_tables[tkey] = tab
     check(lib.s2i_pack_conv_weights_bf16_batched(ptr(tab[0]), tab[1], tab[2], stream()), "s2i_pack_conv_weights_bf16_batched")
@@ -532,7 +525,7 @@ def _rows_view(t):
 def _num_parts(M):
     """Row chunks of the BatchNorm backward reduction: enough blocks to keep the HBM pipes full on the large maps
     (1024 / 2048 / 4096 chunks measured on the bf16 step: no difference)."""
-    return int(max(1, min(int(os.environ.get("S2I_BWD_PARTS", "1024")), M // 64)))
+    return int(max(1, min(1024, M // 64)))
 
 
 # ---- conv + BatchNorm + activation ---------------------------------------------------------------------
@@ -561,9 +554,6 @@ def _dgrad(kind_name, dy, w, packed, n_in, out_dtype=None):
     return y
 
 
-RGB_WGRAD_MFMA = os.environ.get("S2I_RGB_WGRAD", "1") != "0"
-
-
 def _wgrad(kind_name, x, cvec, dy, weight):
     """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode."""
     out, acc = (weight.grad, True) if _direct(weight) else (None, False)
@@ -575,7 +565,7 @@ def _wgrad(kind_name, x, cvec, dy, weight):
             if kind_name == "up":
                 return wgrad_any(CONV_K4S2, dy, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
             g = dy
-            if (RGB_WGRAD_MFMA and x.dtype == torch.bfloat16 and dy.dtype == torch.float32 and dy.shape[-1] <= 4
+            if (x.dtype == torch.bfloat16 and dy.dtype == torch.float32 and dy.shape[-1] <= 4
                     and x.shape[-1] % 8 == 0):
                 # GET_IMAGE_G's weight gradient (bf16 features x fp32 NHWC4 image gradient): the <= 4 channel stream kernel
                 # ran at a tenth of the HBM rate (0.32 ms at 256 px); padded to 8 bf16 channels the image gradient goes
@@ -587,15 +577,6 @@ def _wgrad(kind_name, x, cvec, dy, weight):
             return wgrad_raw(CONV_K4S2, dy, None, x, tuple(weight.shape), swap=1, fold=1, out=out, accumulate=acc)
         return wgrad_raw(_KIND[kind_name], x, cvec, dy, tuple(weight.shape), out=out, accumulate=acc)
 
-    if acc and WGRAD_SIDE_STREAM:
-        cur, side = _wgrad_stream()
-        side.wait_stream(cur)                 # dy (and x) are complete on the backward's stream
-        # the operands stay referenced until join_wgrad_streams(): the caching allocator cannot hand their memory to the
-        # backward's stream while the companion stream still reads it (record_stream's bookkeeping stalled the allocator)
-        _wgrad_keep.setdefault(cur.cuda_stream, []).append((x, cvec, dy))
-        with torch.cuda.stream(side):
-            run()
-        return None
     dw = run()
     return None if acc else dw
 

@@ -17,7 +17,6 @@ What is built differently (MI355X-first):
 The Inception-v3 forwards, IS/FID and image dumps of the reference loop are evaluation-side and out
 of scope; the loop here runs the update and the checkpoint layout only.
 """
-import contextlib
 import os
 import time
 from copy import deepcopy
@@ -167,7 +166,6 @@ class FlatNet:
             p.requires_grad_(flag)
 
     def adam(self, gscale=1.0):
-        ops.join_wgrad_streams()  # weight gradients may still be in flight on their companion streams
         ops.increment(self.step_dev)
         self.step_count += 1
         ops.adam_step(self.p, self.g, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
@@ -251,18 +249,19 @@ class condGANTrainer(object):
         # hipGraph replay of the single-GPU step (S2I_GRAPH=1 or enable_graph()): the step has no host synchronisation and
         # a device-side Adam counter, so after a few eager warm-up steps it is captured once and replayed
         self._graph = None
+        self._labels_dev = None
+        self._g_pass = []
         if os.environ.get("S2I_GRAPH", "0") == "1":
             self.enable_graph()
 
     def _make_d_streams(self):
         """One stream per discriminator; the largest one is the critical path of the step and gets the high priority,
-        so the smaller networks' kernels fill its gaps instead of delaying it (S2I_D_PRIORITY=0: equal priorities).
+        so the smaller networks' kernels fill its gaps instead of delaying it (31.05 vs 31.35 ms / step).
         The streams are shared by every trainer of the process: HIP maps streams onto a few hardware queues, and a second
         trainer with three more streams of its own lost the overlap entirely (35.7 vs 20.7 ms / step, measured)."""
-        prio = os.environ.get("S2I_D_PRIORITY", "1") == "1"
-        key = (torch.cuda.current_device(), self.num_Ds, prio)
+        key = (torch.cuda.current_device(), self.num_Ds)
         if key not in _D_STREAMS:
-            _D_STREAMS[key] = [torch.cuda.Stream(priority=-1 if (prio and i == self.num_Ds - 1) else 0)
+            _D_STREAMS[key] = [torch.cuda.Stream(priority=-1 if i == self.num_Ds - 1 else 0)
                                for i in range(self.num_Ds)]
         return _D_STREAMS[key]
 
@@ -311,7 +310,6 @@ class condGANTrainer(object):
     def _reduce_async(self, flat, lo=0, hi=None):
         if not self.distributed:
             return None
-        ops.join_wgrad_streams()  # the flat gradient buffer must be complete before it is reduced
         g = flat.g if (lo == 0 and hi is None) else flat.g[lo:hi]
         return torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, async_op=True)
 
@@ -359,7 +357,7 @@ class condGANTrainer(object):
             if k == 0 or k >= len(flat.params):
                 continue
             split = flat.offsets[k]
-            if flat.g.numel() - split < int(os.environ.get("S2I_D_OVERLAP_MIN", str(1 << 20))):
+            if flat.g.numel() - split < (1 << 20):
                 continue                                   # a tail below 4 MB is not worth a second collective
             self._d_split[idx] = split
 
@@ -448,60 +446,68 @@ class condGANTrainer(object):
         self._pending = []
 
     # -- G update (trainer.py:429-489) ------------------------------------------------------------------------------
-    def train_Gnet(self, count):
-        self.flatG.zero_grad()
+    def _g_pass_of_d(self, i):
+        """Discriminator i's part of the G update, forward AND backward, on the current stream: the adversarial (and
+        class-aware) loss of the fake image of scale i, and its gradients w.r.t. that image and mu.  The images and mu enter
+        as detached leaves, so this piece of the backward belongs to this discriminator's stream alone; the generator's
+        backward (`_g_backward`) continues from the two gradients.  Same chain rule as one backward over the summed loss
+        (trainer.py:437-446, 487)."""
         u = cfg.TRAIN.COEFF.UNCOND_LOSS
-        errG_total = 0
-        errG_cal_total = 0
-        labels_dev = None
-        per_d = []
-        for f in self.flatsD:
-            f.set_requires_grad(False)  # their weight gradients would be discarded (trainer.py:385)
+        flat = self.flatsD[i]
+        flat.set_requires_grad(False)   # D's weight gradients would be discarded (trainer.py:385)
         try:
-            # the per-scale discriminator passes are independent until their losses are summed: with d_streams each
-            # runs on its own HIP stream (autograd replays every backward on its forward stream)
-            main = torch.cuda.current_stream() if self.d_streams else None
-            if self.d_streams and self._side_streams is None:
-                self._side_streams = self._make_d_streams()
-            for i in range(self.num_Ds):
-                if self.d_streams:
-                    self._side_streams[i].wait_stream(main)  # fake images / mu; D_i's own update is already in order
-                    ctx = torch.cuda.stream(self._side_streams[i])
-                else:
-                    ctx = contextlib.nullcontext()
-                with ctx:
-                    outputs, x_active = self.netsD[i](self.fake_imgs[i], self.mu)
-                    errG = ops.BCELoss.apply(outputs[0], 1.0, 1.0)
-                    if len(outputs) > 1 and u > 0:
-                        errG = errG + ops.BCELoss.apply(outputs[1], 1.0, u)
-                    if cfg.TRAIN.COEFF.CAL_LOSS > 0:
-                        if labels_dev is None:
-                            labels_dev = class_labels_to_device(self.class_labels, x_active.device)
-                        errG = errG + ops.ClassAwareLoss.apply(x_active, labels_dev).reshape(())
-                per_d.append(errG)
-            for i in range(self.num_Ds):
-                if self.d_streams:
-                    main.wait_stream(self._side_streams[i])
-                errG_total = errG_total + per_d[i]
-            if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
-                # colour-consistency between neighbouring scales (trainer.py:455-478); dormant by default
-                coef = cfg.TRAIN.COEFF.COLOR_LOSS
-                for hi, lo in ((-1, -2), (-2, -3)):
-                    if self.num_Ds >= -lo:
-                        mu1, cov1 = compute_mean_covariance(self.fake_imgs[hi])
-                        mu2, cov2 = compute_mean_covariance(self.fake_imgs[lo].detach())
-                        errG_total = errG_total + coef * nn.functional.mse_loss(mu1, mu2) \
-                            + coef * 5 * nn.functional.mse_loss(cov1, cov2)
-            kl_loss = KL_loss(self.mu, self.logvar) * cfg.TRAIN.COEFF.KL
-            errG_total = errG_total + kl_loss + errG_cal_total
-            split = getattr(self, '_g_split', None) if self.distributed else None
-            self._g_tail_work = None
-            self._g_hook_armed = split is not None
-            errG_total.backward()
-            self._g_hook_armed = False
+            fake = self.fake_imgs[i].detach().requires_grad_(True)
+            mu = self.mu.detach().requires_grad_(True)
+            outputs, x_active = self.netsD[i](fake, mu)
+            errG = ops.BCELoss.apply(outputs[0], 1.0, 1.0)
+            if len(outputs) > 1 and u > 0:
+                errG = errG + ops.BCELoss.apply(outputs[1], 1.0, u)
+            if cfg.TRAIN.COEFF.CAL_LOSS > 0:
+                if self._labels_dev is None:
+                    self._labels_dev = class_labels_to_device(self.class_labels, x_active.device)
+                errG = errG + ops.ClassAwareLoss.apply(x_active, self._labels_dev).reshape(())
+            g_fake, g_mu = torch.autograd.grad(errG, [fake, mu], allow_unused=True)
         finally:
-            for f in self.flatsD:
-                f.set_requires_grad(True)
+            flat.set_requires_grad(True)
+        self._g_pass[i] = (errG.detach(), g_fake, g_mu)
+
+    def _g_backward(self):
+        """The generator's own part of the G update on the current stream (after every `_g_pass_of_d`): KL term, the
+        backward from the image gradients, all-reduce, Adam."""
+        self.flatG.zero_grad()
+        errG_total = 0
+        roots, grads = [], []
+        g_mu_total = None
+        for i in range(self.num_Ds):
+            errG, g_fake, g_mu = self._g_pass[i]
+            errG_total = errG_total + errG
+            roots.append(self.fake_imgs[i])
+            grads.append(g_fake)
+            if g_mu is not None:
+                g_mu_total = g_mu if g_mu_total is None else g_mu_total + g_mu
+        self._g_pass = [None] * self.num_Ds
+        extra = 0
+        if cfg.TRAIN.COEFF.COLOR_LOSS > 0:
+            # colour-consistency between neighbouring scales (trainer.py:455-478); dormant by default
+            coef = cfg.TRAIN.COEFF.COLOR_LOSS
+            for hi, lo in ((-1, -2), (-2, -3)):
+                if self.num_Ds >= -lo:
+                    mu1, cov1 = compute_mean_covariance(self.fake_imgs[hi])
+                    mu2, cov2 = compute_mean_covariance(self.fake_imgs[lo].detach())
+                    extra = extra + coef * nn.functional.mse_loss(mu1, mu2) + coef * 5 * nn.functional.mse_loss(cov1, cov2)
+        kl_loss = KL_loss(self.mu, self.logvar) * cfg.TRAIN.COEFF.KL
+        own = kl_loss + extra
+        errG_total = errG_total + own.detach()
+        if g_mu_total is not None:
+            roots.append(self.mu)
+            grads.append(g_mu_total)
+        roots.append(own)
+        grads.append(torch.ones_like(own))
+        split = getattr(self, '_g_split', None) if self.distributed else None
+        self._g_tail_work = None
+        self._g_hook_armed = split is not None
+        torch.autograd.backward(roots, grads)
+        self._g_hook_armed = False
         if self.distributed and self._g_tail_work is not None:
             work = self._reduce_async(self.flatG, 0, split)   # head chunk: ca_net, fc, upsample1
             work.wait()
@@ -512,20 +518,44 @@ class condGANTrainer(object):
             if work is not None:
                 work.wait()
         self.flatG.adam(1.0 / self.world)
-        return kl_loss, errG_total
+        return kl_loss.detach(), errG_total
+
+    def train_Gnet(self, count):
+        """One generator update: every discriminator's pass on its own HIP stream (forward, losses, backward to the fake
+        image), then the generator's backward and Adam on the current stream."""
+        self._labels_dev = None
+        self._g_pass = [None] * self.num_Ds
+        main = torch.cuda.current_stream() if self.d_streams else None
+        if self.d_streams and self._side_streams is None:
+            self._side_streams = self._make_d_streams()
+        for i in range(self.num_Ds):
+            if self.d_streams:
+                self._side_streams[i].wait_stream(main)  # fake images / mu; D_i's own update is already in order
+                with torch.cuda.stream(self._side_streams[i]):
+                    self._g_pass_of_d(i)
+            else:
+                self._g_pass_of_d(i)
+        if self.d_streams:
+            for i in range(self.num_Ds):
+                main.wait_stream(self._side_streams[i])
+        return self._g_backward()
 
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
     def enable_graph(self, warmup=3):
-        """Capture the train step in a hipGraph after `warmup` eager steps and replay it from then on (single process
-        only: an RCCL all-reduce inside a captured graph is not exercised here).  Launch-bound otherwise: ~900 launches
-        of 5-300 us each per step, enqueued from Python."""
+        """Replay the single-GPU step from hipGraphs after `warmup` eager steps.  The step is cut where its HIP streams
+        fork and join, and every piece is captured as a graph of ONE stream: the generator forward (main stream), per
+        discriminator its update followed by its pass of the G update (that discriminator's stream), the generator's
+        backward + Adam + EMA (main stream).  The pieces are launched like kernels -- stream waits between them -- so the
+        three discriminator streams stay concurrent (one graph of the whole step replays its forked branches one after
+        another on ROCm 7.2: DESIGN.md section 12).  Single process only: an RCCL all-reduce inside a captured graph is
+        not exercised here."""
         # warm-up and capture run on one private stream: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and one that lives on the (non-capturing) default stream invalidates the capture
-        self._graph = dict(warmup=warmup, seen=0, graph=None, stream=torch.cuda.Stream())
+        self._graph = dict(warmup=warmup, seen=0, graphs=None, stream=torch.cuda.Stream())
 
     def _graph_signature(self, real_imgs, wrong_imgs, txt_embedding, noise, eps):
         ts = list(real_imgs) + list(wrong_imgs) + [txt_embedding, noise] + ([eps] if eps is not None else [])
-        return tuple((tuple(t.shape), t.dtype) for t in ts) + (ops.ACT_BF16, ops.MATH_PLANES)
+        return tuple((tuple(t.shape), t.dtype) for t in ts) + (ops.ACT_BF16, ops.MATH_PLANES, bool(txt_embedding.requires_grad))
 
     def _capture(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps):
         st = self._graph
@@ -540,15 +570,34 @@ class condGANTrainer(object):
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=st['stream']):
-            with ops.param_grad_mode(True, False):
-                out = self._train_step(static['real'], static['wrong'], static['emb'], static['labels'], static['noise'],
-                                       static['eps'])
-            outs = [o.detach().reshape(()) for o in out]
-        del out
-        st.update(graph=graph, static=static, outs=outs, sig=self._graph_signature(real_imgs, wrong_imgs, txt_embedding,
-                                                                                    noise, eps))
+        ops.pin_graph_resources()      # workspaces and pack tables referenced by the graphs are never freed from here on
+        main = st['stream']
+        if self._side_streams is None:
+            self._side_streams = self._make_d_streams()
+        n = self.num_Ds
+        # one memory pool per stream: pieces that replay concurrently must not share freed blocks
+        pools = [torch.cuda.graph_pool_handle() for _ in range(n + 1)]
+        graphs = dict(fwd=torch.cuda.CUDAGraph(), d=[torch.cuda.CUDAGraph() for _ in range(n)], g=torch.cuda.CUDAGraph())
+        errs = [None] * n
+        with ops.param_grad_mode(True):
+            with torch.cuda.graph(graphs['fwd'], pool=pools[n], stream=main):
+                self._begin_step(static['real'], static['wrong'], static['emb'], static['labels'])
+                self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(static['noise'], static['emb'], static['eps'])
+            for i in reversed(range(n)):
+                with torch.cuda.graph(graphs['d'][i], pool=pools[i], stream=self._side_streams[i]):
+                    errs[i] = self.train_Dnet(i, 0).detach()
+                    self._g_pass_of_d(i)
+            with torch.cuda.graph(graphs['g'], pool=pools[n], stream=main):
+                kl_loss, errG_total = self._g_backward()
+                self.flatG.ema(0.999)
+                errD_total = 0
+                for e in reversed(errs):        # the eager step's order: largest discriminator first
+                    errD_total = errD_total + e
+                outs = [o.detach().reshape(()) for o in (errD_total, errG_total, kl_loss)]
+        for f in [self.flatG] + self.flatsD:
+            f.step_count -= 1          # FlatNet.adam counted a step the capture did not execute; the replay below counts it
+        st.update(graphs=graphs, static=static, outs=outs, pools=pools,
+                  sig=self._graph_signature(real_imgs, wrong_imgs, txt_embedding, noise, eps))
         # the capture itself did not execute anything: replay once so that this call IS a step
         return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps, fresh=True)
 
@@ -570,47 +619,66 @@ class condGANTrainer(object):
             if eps is not None:
                 put(s['eps'], eps)
             put(s['labels'], class_labels_to_device(class_labels, noise.device))
-        st['graph'].replay()
+        g = st['graphs']
+        main = torch.cuda.current_stream()
+        g['fwd'].replay()
+        for i in reversed(range(self.num_Ds)):    # largest first, as the eager step enqueues them
+            side = self._side_streams[i]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                g['d'][i].replay()
+        for i in range(self.num_Ds):
+            main.wait_stream(self._side_streams[i])
+        g['g'].replay()
         for f in [self.flatG] + self.flatsD:
             f.step_count += 1
         if txt_embedding.requires_grad and s['emb'].grad is not None:
-            txt_embedding.grad = s['emb'].grad
+            txt_embedding.grad = s['emb'].grad.clone()     # the static gradient buffer is overwritten by the next replay
         return tuple(st['outs'])
 
     def train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
         st = self._graph
-        if st is not None and not self.distributed and torch.cuda.is_available():
-            if st['graph'] is not None:
+        if st is not None and not self.distributed and torch.cuda.is_available() and self.d_streams:
+            if st['graphs'] is not None:
                 if st['sig'] == self._graph_signature(real_imgs, wrong_imgs, txt_embedding, noise, eps):
                     return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
-                # another batch shape (ragged last batch of an epoch): eager
+                # another batch shape (ragged last batch of an epoch): an eager step.  The replays bypassed the host-side
+                # bookkeeping of the derived weight copies (bf16 / split planes, keyed by plan layout, and another batch
+                # plans other layouts): drop them all, they are re-derived from the current masters on first use.
+                for f in [self.flatG] + self.flatsD:
+                    ops.invalidate_derived(f.params)
             elif st['seen'] >= st['warmup']:
                 return self._capture(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
             else:
                 st['seen'] += 1
                 gs, cur = st['stream'], torch.cuda.current_stream()
                 gs.wait_stream(cur)
-                with torch.cuda.stream(gs), ops.param_grad_mode(
-                        True, self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"):
+                with torch.cuda.stream(gs), ops.param_grad_mode(True):
                     out = self._train_step(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
                 cur.wait_stream(gs)
                 return out
-        # kernels accumulate into the flat gradient buffers (zeroed per update); the switches are scoped to the step, so
+        # kernels accumulate into the flat gradient buffers (zeroed per update); the switch is scoped to the step, so
         # a later stock-optimiser use of the modules in this process gets autograd-returned gradients again.
-        # S2I_WGRAD_STREAM=1 is a rejected experiment, slower than the default.
-        with ops.param_grad_mode(True, self.d_streams and os.environ.get("S2I_WGRAD_STREAM", "0") == "1"):
+        with ops.param_grad_mode(True):
             return self._train_step(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps)
 
-    def _train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
+    def _begin_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels):
         self.real_imgs, self.wrong_imgs = real_imgs, wrong_imgs
         self.txt_embedding, self.class_labels = txt_embedding, class_labels
+        # class labels on the device once per step, on the main stream, before the discriminator streams fork
+        self._labels_dev = (class_labels_to_device(class_labels, txt_embedding.device)
+                            if cfg.TRAIN.COEFF.CAL_LOSS > 0 else None)
+        self._g_pass = [None] * self.num_Ds
+
+    def _train_step(self, real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps=None):
+        self._begin_step(real_imgs, wrong_imgs, txt_embedding, class_labels)
         self.fake_imgs, self.mu, self.logvar = _unwrap(self.netG)(noise, txt_embedding, eps)
         errD_total = 0
         if self.d_streams and self.num_Ds >= 2:
             # the D updates are independent: each runs on its own HIP stream (zero, stacked forward, backward,
             # all-reduce, Adam, re-pack), so the many short kernels of one fill the idle CUs of the others.  The
-            # same stream later carries that discriminator's pass of the G update, so D_i's part of the G update
-            # can start as soon as D_i is updated, while a larger discriminator is still in its own update.
+            # same stream then carries that discriminator's pass of the G update (forward, losses, backward to the fake
+            # image), which can start as soon as D_i is updated, while a larger discriminator is still in its own update.
             main = torch.cuda.current_stream()
             if self._side_streams is None:
                 self._side_streams = self._make_d_streams()
@@ -620,12 +688,19 @@ class condGANTrainer(object):
                 st.wait_stream(main)
                 with torch.cuda.stream(st):
                     errs.append(self.train_Dnet(i, 0))
+            for i in range(self.num_Ds):
+                with torch.cuda.stream(self._side_streams[i]):
+                    self._g_pass_of_d(i)
+            for i in range(self.num_Ds):
+                main.wait_stream(self._side_streams[i])
         else:
             # largest first, so that its gradient all-reduce (285 MB for D_NET256) hides behind the smaller
             # discriminators' forward/backward
             errs = [self.train_Dnet(i, 0, defer_step=True) for i in reversed(range(self.num_Ds))]
             self._flush_d_steps()
-        kl_loss, errG_total = self.train_Gnet(0)  # joins the discriminator streams before its backward
+            for i in range(self.num_Ds):
+                self._g_pass_of_d(i)
+        kl_loss, errG_total = self._g_backward()
         self.flatG.ema(0.999)
         for e in errs:
             errD_total = errD_total + e

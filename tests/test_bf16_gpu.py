@@ -77,7 +77,7 @@ CONV_CASES = [
 ]
 
 
-# cases for the 256-pixel second-generation kernel (S2I_B16_V2=2: wherever it can run; S2I_B16_PERSISTENT=4: four block
+# cases for the 256-pixel second-generation kernel (tuning knobs b16_v2=2: wherever it can run; b16_persist=4: four block
 # slots, so that a block walks several tiles)
 V2_CASES = [
     ("k4s2", 3, 64, 64, 128),         # 12 tiles of 8x32 outputs over 4 persistent blocks: top / bottom halo rows, 2 chunks
@@ -94,12 +94,12 @@ V2_CASES = [
 
 
 @pytest.mark.parametrize("case", V2_CASES, ids=lambda c: "-".join(str(v) for v in c))
-def test_bf16_conv_second_generation_kernels(gpu, case, monkeypatch):
+def test_bf16_conv_second_generation_kernels(gpu, case):
     """The same check through conv_bf16_v2_kernel, forced wherever it is eligible, with few enough block slots that the
     persistent form walks several tiles per block."""
-    monkeypatch.setenv("S2I_B16_V2", "2")
-    monkeypatch.setenv("S2I_B16_PERSISTENT", "4")
-    _conv_case(gpu, case)
+    from speech_to_image_translation_without_text_amd import _lib
+    with _lib.tuning(b16_v2=2, b16_persist=4):
+        _conv_case(gpu, case)
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(str(v) for v in c))
@@ -176,12 +176,12 @@ BLOCK_CASES = [
 
 @pytest.mark.parametrize("case", [BLOCK_CASES[0], BLOCK_CASES[1], BLOCK_CASES[4]],
                          ids=lambda c: "-".join(str(v) for v in c))
-def test_bf16_fused_block_second_generation_kernels(gpu, case, bf16_mode, monkeypatch):
+def test_bf16_fused_block_second_generation_kernels(gpu, case, bf16_mode):
     """The fused block (class-bias epilogue, BatchNorm sums per tile, both gradients) through conv_bf16_v2_kernel: the three
     block cases with more than 64 output channels."""
-    monkeypatch.setenv("S2I_B16_V2", "2")
-    monkeypatch.setenv("S2I_B16_PERSISTENT", "4")
-    _block_case(gpu, case)
+    from speech_to_image_translation_without_text_amd import _lib
+    with _lib.tuning(b16_v2=2, b16_persist=4):
+        _block_case(gpu, case)
 
 
 @pytest.mark.parametrize("case", BLOCK_CASES, ids=lambda c: "-".join(str(v) for v in c))

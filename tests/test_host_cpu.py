@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in s2i_hip.h but not exported: %s" % missing
     unbound = sorted(declared - set(_lib.EXPORTED_SYMBOLS))
     assert not unbound, "declared in s2i_hip.h but not bound in _lib.py: %s" % unbound
-    assert lib.s2i_version() == _lib.ABI_VERSION == 2
+    assert lib.s2i_version() == _lib.ABI_VERSION == 3
 
 
 def test_descriptor_validation_reports_errors_without_a_gpu():
@@ -132,3 +132,25 @@ def test_header_is_valid_c(tmp_path):
     src.write_text('#include "s2i_hip.h"\nint main(void) { s2i_conv_desc c; s2i_wgrad_desc w; (void)c; (void)w; return 0; }\n')
     subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", str(src), "-o",
                     str(tmp_path / "h.o")], check=True)
+
+
+def test_tuning_knobs_roundtrip_without_a_gpu():
+    """s2i_set_tuning / s2i_get_tuning (the planners' integer knobs; the library reads no environment variable on a launch
+    path) and the descriptor's tile_rows: unknown keys and values are rejected with a message."""
+    import ctypes
+    from speech_to_image_translation_without_text_amd import _lib
+    lib = _lib.load()
+    with _lib.tuning(fwd_bm=96, b16_v2=2):
+        v = ctypes.c_int(0)
+        assert lib.s2i_get_tuning(b"fwd_bm", ctypes.byref(v)) == 0 and v.value == 96
+    v = ctypes.c_int(0)
+    assert lib.s2i_get_tuning(b"fwd_bm", ctypes.byref(v)) == 0 and v.value == -1     # restored: unset
+    assert lib.s2i_set_tuning(b"no_such_knob", 1) != 0 and b"no_such_knob" in lib.s2i_last_error()
+    d = _lib.ConvDesc(_lib.CONV_K3S1, 2, 8, 8, 64, 0, 128, 0, 0, 64, 128, 0, 1, 128, 1, 1, 0, 0, 0, 64)
+    assert lib.s2i_conv_stat_parts(ctypes.byref(d)) < 0 and b"tile_rows" in lib.s2i_last_error()
+    d.tile_rows = 96          # 128 rows: too few for two 96-row tiles, the planner keeps 128
+    assert lib.s2i_conv_stat_parts(ctypes.byref(d)) == 1
+    big = _lib.ConvDesc(_lib.CONV_K4S2, 72, 64, 64, 128, 0, 256, 0, 0, 128, 256, 0, 1, 256, 3, 0, 0, 0, 0, 0)
+    assert lib.s2i_conv_stat_parts(ctypes.byref(big)) == 72 * 32 * 32 // 96      # the stacked passes take 96-row tiles
+    big.tile_rows = 128
+    assert lib.s2i_conv_stat_parts(ctypes.byref(big)) == 72 * 32 * 32 // 128

@@ -422,12 +422,10 @@ def test_split_bf16_products_against_fp64(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("act", ["none", "glu", "lrelu"])
-def test_batchnorm_pass_forms_agree(gpu, act, dtype, monkeypatch):
-    """The BatchNorm / activation passes exist in several forms (activation as a template constant vs a runtime switch,
-    row walker vs grid-stride apply, row-tiled vs flat forward: DESIGN.md section 11).  On the same inputs the specialised
-    backward reduce must equal the runtime form bit for bit (same operations in the same order), the other pairs within
-    float rounding of a differently contracted expression."""
-    import ctypes
+def test_batchnorm_passes_against_formulas(gpu, act, dtype):
+    """The three BatchNorm / activation passes (forward apply, backward column reduction, backward apply) on raw buffers with
+    three BatchNorm groups, against their formulas evaluated in fp64 by torch: out = act(s y + t);
+    part = (sum dz, sum dz xhat) per group; dy = s (dz - m0 - xhat m1)."""
     from speech_to_image_translation_without_text_amd import ops
     from speech_to_image_translation_without_text_amd._lib import ACT_GLU, ACT_LRELU, ACT_NONE, DT_BF16, DT_F32, check, ptr, stream
     lib = ops._lib_ready()
@@ -442,35 +440,34 @@ def test_batchnorm_pass_forms_agree(gpu, act, dtype, monkeypatch):
     coef[:, 1].abs_().add_(0.5)
     red2 = torch.randn(G, 2, C, device=gpu, generator=g) * 0.1
     nparts = 4 * G
-
-    def reduce_():
-        part = torch.zeros(2, nparts, C, device=gpu)
-        check(lib.s2i_bn_act_bwd_reduce_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), a, ptr(part), nparts, stream()), "reduce")
-        return part
-
-    def apply_():
-        dy = torch.empty(M, C, device=gpu, dtype=tdt)
-        check(lib.s2i_bn_act_bwd_apply_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), ptr(red2), a, ptr(dy), stream()), "apply")
-        return dy.float()
-
-    def forward_():
-        out = torch.empty(M, Co, device=gpu, dtype=tdt)
-        check(lib.s2i_bn_act_forward_dt(dt, ptr(y), M, G, C, ptr(coef), a, None, ptr(out), stream()), "forward")
-        return out.float()
-
-    results = {}
-    for name, env in (("default", {}), ("runtime", {"S2I_EW_SPEC": "0", "S2I_EW_WALK": "0", "S2I_EW_ROWS": "0"}),
-                      ("rows", {"S2I_EW_ROWS": "31", "S2I_EW_WALK": "0"})):
-        for k in ("S2I_EW_SPEC", "S2I_EW_WALK", "S2I_EW_ROWS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        results[name] = (reduce_(), apply_(), forward_())
+    part = torch.zeros(2, nparts, C, device=gpu)
+    check(lib.s2i_bn_act_bwd_reduce_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), a, ptr(part), nparts, stream()), "reduce")
+    dy = torch.empty(M, C, device=gpu, dtype=tdt)
+    check(lib.s2i_bn_act_bwd_apply_dt(dt, ptr(y), ptr(dout), Co, M, G, C, ptr(coef), ptr(red2), a, ptr(dy), stream()), "apply")
+    out = torch.empty(M, Co, device=gpu, dtype=tdt)
+    check(lib.s2i_bn_act_forward_dt(dt, ptr(y), M, G, C, ptr(coef), a, None, ptr(out), stream()), "forward")
     torch.cuda.synchronize()
-    assert torch.equal(results["default"][0], results["runtime"][0]), "specialised backward reduce differs from the runtime form"
-    tol = 2e-2 if dtype == "bf16" else 1e-5    # bf16: a final rounding may fall the other way
-    for i, what in ((0, "reduce"), (1, "apply"), (2, "forward")):
-        for other in ("runtime", "rows"):
-            ref, got = results["default"][i], results[other][i]
-            scale = float(ref.abs().max()) + 1e-12
-            assert float((ref - got).abs().max()) <= tol * scale, (what, other, float((ref - got).abs().max()), scale)
+
+    yd, dd = y.double().view(G, M // G, C), dout.double().view(G, M // G, Co)
+    mean, istd, sc, sh = (coef[:, k].double().view(G, 1, C) for k in range(4))
+    z = sc * yd + sh
+    xh = (yd - mean) * istd
+    if a == ACT_GLU:
+        h = C // 2
+        sg = torch.sigmoid(z[..., h:])
+        ref_out = z[..., :h] * sg
+        dz = torch.cat((dd * sg, dd * z[..., :h] * sg * (1 - sg)), -1)
+    elif a == ACT_LRELU:
+        ref_out = torch.where(z > 0, z, 0.2 * z)
+        dz = torch.where(z > 0, dd, 0.2 * dd)
+    else:
+        ref_out, dz = z, dd
+    ref_dy = sc * (dz - red2[:, 0].double().view(G, 1, C) - xh * red2[:, 1].double().view(G, 1, C))
+    ref_part = torch.stack((dz.sum(1), (dz * xh).sum(1)))            # (2, G, C)
+    got_part = part.double().view(2, G, nparts // G, C).sum(2)
+    tol = 2e-2 if dtype == "bf16" else 1e-5    # bf16: the results are rounded to 8 significant bits
+    for what, got, ref in (("forward", out.double().view(G, -1, Co), ref_out), ("apply", dy.double().view(G, -1, C), ref_dy),
+                           ("reduce", got_part, ref_part)):
+        scale = float(ref.abs().max()) + 1e-12
+        rt = 1e-4 if what == "reduce" else tol
+        assert float((ref - got).abs().max()) <= rt * scale, (what, float((ref - got).abs().max()), scale)

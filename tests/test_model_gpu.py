@@ -625,7 +625,7 @@ def test_hip_graph_replay_matches_eager(gpu, bf16):
                 gemb = emb.grad.detach().clone()
             torch.cuda.synchronize()
             if graphed:
-                assert tr._graph['graph'] is not None
+                assert tr._graph['graphs'] is not None
             state = [tr.flatG.p.clone(), tr.flatG.m.clone(), tr.flatG.v.clone(), tr.flatG.avg.clone()]
             state += [f.p.clone() for f in tr.flatsD] + [f.v.clone() for f in tr.flatsD]
             state += [netsD[2].state_dict()['img_code_s64_2.1.running_var'].clone(),
@@ -636,3 +636,46 @@ def test_hip_graph_replay_matches_eager(gpu, bf16):
     for a, c in zip(*finals):
         assert torch.equal(a, c)
     assert int(finals[1][-3]) == 5
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_graph_replays_interleaved_with_ragged_eager_steps(gpu, bf16):
+    """Graph replays update the weights and re-derive the packed / bf16 copies on the device without running the host-side
+    cache bookkeeping; an eager step of ANOTHER batch shape in between (the ragged last batch of an epoch: un-stacked
+    discriminator passes, other kernel plans, other bf16 weight layouts) must still see current weights, and so must the
+    second such step.  Replay, ragged eager step, replays, ragged eager step, replay == the same sequence all eager."""
+    from speech_to_image_translation_without_text_amd import ops, trainer as T
+    case = dict(CASES['small3'], B=8)
+    old = ops.ACT_BF16
+    ops.ACT_BF16 = bf16
+    sizes = [8, 8, 8, 8, 5, 8, 8, 5, 8]          # warm-up x2, capture, replay, ragged, replay x2, ragged, replay
+    finals = []
+    try:
+        for graphed in (False, True):
+            netG, netsD = build_nets(case)
+            netG.to(gpu)
+            for d in netsD:
+                d.to(gpu)
+            tr = T.condGANTrainer(None, None, 256, False)
+            tr.build(netG, netsD)
+            if graphed:
+                tr.enable_graph(warmup=2)
+            gen = torch.Generator(device=gpu).manual_seed(9)
+            losses = []
+            for B in sizes:
+                noise = torch.randn(B, case['z'], device=gpu, generator=gen)
+                eps = torch.randn(B, case['ef'], device=gpu, generator=gen)
+                real = [torch.rand(B, 3, 64 << i, 64 << i, device=gpu, generator=gen) * 2 - 1 for i in range(3)]
+                wrong = [torch.rand(B, 3, 64 << i, 64 << i, device=gpu, generator=gen) * 2 - 1 for i in range(3)]
+                emb = torch.randn(B, case['t'], device=gpu, generator=gen)
+                out = tr.train_step(real, wrong, emb, [k % 3 for k in range(B)], noise, eps)
+                losses.append(torch.stack([o.detach().reshape(()) for o in out]).clone())
+            torch.cuda.synchronize()
+            if graphed:
+                assert tr._graph['graphs'] is not None
+            assert tr.flatG.step_count == len(sizes) and int(tr.flatG.step_dev) == len(sizes)
+            finals.append([tr.flatG.p.clone(), tr.flatG.avg.clone()] + [f.p.clone() for f in tr.flatsD] + [torch.stack(losses)])
+    finally:
+        ops.ACT_BF16 = old
+    for a, c in zip(*finals):
+        assert torch.equal(a, c)

@@ -506,7 +506,7 @@ def test_step_scopes_the_direct_gradient_switches(gpu):
     tr.build(netG, netsD)
     b = to_dev(batch, gpu)
     tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], b['noise'], b['eps'])
-    assert ops.DIRECT_PARAM_GRAD is False and ops.WGRAD_SIDE_STREAM is False
+    assert ops.DIRECT_PARAM_GRAD is False
     # the facade refuses to step once torch's zero_grad has detached the flat views
     netsD[0].zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):

@@ -1,5 +1,5 @@
 """Per-layer timing of the bf16 convolution kernels on the shapes of BASELINE config 4 (dev tool, GPU box only).
-usage: python tools/conv16_bench.py [batch]      (kernel variants: S2I_B16_VARIANT=0|1|2)"""
+usage: python tools/conv16_bench.py [batch]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +22,7 @@ LAYERS = [
     ("G up4 fwd", TCONV_K4S2, B, 32, 128, 128, 0), ("G up3 fwd", TCONV_K4S2, B, 16, 256, 256, 0),
     ("G h3 up dgrad", CONV_K4S2, B, 256, 32, 32, 1), ("G h2 up dgrad", CONV_K4S2, B, 128, 64, 64, 1),
 ]
-print("variant", os.environ.get("S2I_B16_VARIANT", "0"), "batch", B)
+print("batch", B)
 for name, kind, n, H, Cin, Cout, wmode in LAYERS:
     x = torch.randn(n, H, H, Cin, device=dev).to(torch.bfloat16)
     T = {CONV_K3S1: 9, CONV_K4S2: 16, TCONV_K4S2: 16}[kind]

@@ -1,16 +1,21 @@
 """In-kernel timeline of the bf16 convolution kernel on D256 conv2 (dev tool, GPU box only): launches the diagnostic
-instantiation (S2I_B16_DBG=32: wave 0 of every block stamps s_memtime at the phase boundaries) and prints where a block's
-lifetime goes.  Shares are what to read, not the run time of this build (the stamps fence overlaps the real kernel has).
-usage: python tools/conv16_timeline.py [batch]"""
+instantiation (libs2i_hip_diag.so, `make -C csrc diag`; knob b16_dbg=32: wave 0 of every block stamps s_memtime at the phase
+boundaries) and prints where a block's lifetime goes.  Shares are what to read, not the run time of this build (the stamps
+fence overlaps the real kernel has).
+usage: python tools/conv16_timeline.py [batch] [v1]"""
 import os, sys
-os.environ["S2I_B16_DBG"] = "32"
 OUT = os.environ.setdefault("S2I_B16_TIMELINE", "/tmp/conv_timeline.bin")
 import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from speech_to_image_translation_without_text_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libs2i_hip_diag.so")     # the diagnostic build
 from speech_to_image_translation_without_text_amd import ops
 from speech_to_image_translation_without_text_amd._lib import CONV_K4S2, PACK_PLAIN
+V1 = "v1" in sys.argv[2:]
+_lib.check(_lib.load().s2i_set_tuning(b"b16_dbg", 32), "s2i_set_tuning")
+_lib.check(_lib.load().s2i_set_tuning(b"b16_v2", 0 if V1 else 1), "s2i_set_tuning")
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 48
 dev = torch.device("cuda:0")
@@ -23,7 +28,7 @@ torch.cuda.synchronize()
 t = np.fromfile(OUT, dtype=np.uint64).reshape(-1, 64).astype(np.int64)
 nb = t.shape[0]
 print("blocks", nb)
-if os.environ.get("S2I_B16_V2", "1") != "0":
+if not V1:
     # conv_bf16_v2_kernel: 0 start, 1 plan done, 2 prologue loads issued, 3 prologue stored + barrier,
     # 4 + 2 s / 5 + 2 s: stage s before / after its closing barrier, 50 / 51 / 52 epilogue
     life = t[:, 52] - t[:, 0]

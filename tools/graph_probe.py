@@ -1,21 +1,37 @@
-"""Does the train step capture into a hipGraph under the current environment switches?  (dev tool; run one variant per
-process: a failing capture can take the process down)"""
+"""Replay-vs-eager probe (dev tool, GPU box only): runs the sequence of tests/test_model_gpu.py::
+test_graph_replays_interleaved_with_ragged_eager_steps eagerly and with graph replay and prints, per step, whether the
+losses agree bit for bit, then the largest difference per state tensor."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import CASES, build_nets, make_batch
+from helpers import CASES, build_nets
 from speech_to_image_translation_without_text_amd import ops, trainer as T
-dev = torch.device("cuda:0")
+gpu = torch.device("cuda:0")
+ops.ACT_BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"
 case = dict(CASES['small3'], B=8)
-netG, netsD = build_nets(case); batch = make_batch(case)
-netG.to(dev); [d.to(dev) for d in netsD]
-tr = T.condGANTrainer(None, None, 256, False); tr.build(netG, netsD)
-if os.environ.get("PROBE_NUM_D"):
-    n = int(os.environ["PROBE_NUM_D"]); tr.netsD, tr.flatsD, tr.num_Ds = tr.netsD[:n], tr.flatsD[:n], n
-tr.enable_graph(warmup=2)
-b = {k: ([t.to(dev) for t in v] if isinstance(v, list) and torch.is_tensor(v[0]) else (v.to(dev) if torch.is_tensor(v) else v)) for k, v in batch.items()}
-for it in range(5):
-    out = tr.train_step(b['real'], b['wrong'], b['emb'].clone().requires_grad_(True), batch['labels'], b['noise'], b['eps'])
+sizes = [8, 8, 8, 8, 5, 8, 8, 5, 8]
+runs = []
+for graphed in (False, True):
+    netG, netsD = build_nets(case)
+    netG.to(gpu); [d.to(gpu) for d in netsD]
+    tr = T.condGANTrainer(None, None, 256, False); tr.build(netG, netsD)
+    if graphed:
+        tr.enable_graph(warmup=2)
+    gen = torch.Generator(device=gpu).manual_seed(9)
+    losses, states = [], []
+    for B in sizes:
+        noise = torch.randn(B, case['z'], device=gpu, generator=gen); eps = torch.randn(B, case['ef'], device=gpu, generator=gen)
+        real = [torch.rand(B, 3, 64 << i, 64 << i, device=gpu, generator=gen) * 2 - 1 for i in range(3)]
+        wrong = [torch.rand(B, 3, 64 << i, 64 << i, device=gpu, generator=gen) * 2 - 1 for i in range(3)]
+        emb = torch.randn(B, case['t'], device=gpu, generator=gen)
+        out = tr.train_step(real, wrong, emb, [k % 3 for k in range(B)], noise, eps)
+        losses.append(torch.stack([o.detach().reshape(()) for o in out]).clone())
+        states.append([tr.flatG.p.clone()] + [f.p.clone() for f in tr.flatsD])
     torch.cuda.synchronize()
-    print("step", it, [round(float(o), 5) for o in out], "graph" if tr._graph['graph'] is not None else "eager", flush=True)
+    runs.append((losses, states))
+for k, B in enumerate(sizes):
+    la, lb = runs[0][0][k], runs[1][0][k]
+    print("step %d B=%d losses equal %s  %s | params max diff %s" % (
+        k, B, bool(torch.equal(la, lb)), (la - lb).abs().tolist(),
+        [float((a - b).abs().max()) for a, b in zip(runs[0][1][k], runs[1][1][k])]), flush=True)
