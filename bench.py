@@ -41,9 +41,9 @@ def parse():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
     ap.add_argument("--graph", type=int, default=0,
-                    help="1: capture the single-GPU step in a hipGraph after the first warm-up steps and replay it (measured "
-                         "SLOWER on ROCm 7.2: the replay serialises the per-discriminator streams, DESIGN.md); 0 (default): "
-                         "enqueue every launch from Python")
+                    help="single-GPU step recorded by stream capture after the first warm-up steps: 1 = re-issued as plain "
+                         "launches from C, one call per stream piece (s2i_plan_replay); 2 = hipGraphLaunch of each piece "
+                         "(measured slower than the Python step on ROCm 7.2, DESIGN.md); 0: enqueue every launch from Python")
     ap.add_argument("--no-side-leg", action="store_true", help="skip the extra bf16x3 measurement of f32 runs (profiling)")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16", "bf16p"],
                     help="matrix products of the conv GEMMs: native fp32 MFMA (default), or fp32 operands split into 3 / 2 "
@@ -300,7 +300,7 @@ def main():
     tr = T.condGANTrainer(None, None, 256, False, local_rank=local_rank, distributed=distributed)
     tr.build(netG, netsD)
     if args.graph and not distributed:
-        tr.enable_graph(warmup=2)
+        tr.enable_graph(warmup=2, executor="plan" if args.graph == 1 else "graph")
 
     t_start = time.perf_counter()
     batch, gen = synthetic_batch(B, dev, 1 + rank)
@@ -422,7 +422,7 @@ def main():
                 try:
                     ops.MATH_PLANES = 3
                     if tr._graph is not None:
-                        tr.enable_graph(warmup=2)   # a graph of its own for this mode
+                        tr.enable_graph(warmup=2, executor=tr._graph.get("executor", "plan"))   # a recording of its own for this mode
                     el3, out3 = timed(4, args.steps)
                     line["bf16x3_split"] = {"value": round(B * args.steps / el3, 2), "unit": "images/sec",
                                             "ms_per_step": round(el3 / args.steps * 1e3, 3), "note": MATH_NOTE["bf16x3"]}

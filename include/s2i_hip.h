@@ -388,6 +388,19 @@ int s2i_scale_dev(float* y, const float* x, long long n, const float* a_dev, voi
 /* y = a*x (+ y) elementwise helpers used for gradient averaging and accumulation */
 int s2i_axpby(float* y, const float* x, long long n, float a, float b, void* stream);
 
+/* ---- launch-plan replay (host-side machinery of this build; the reference's loop body, trainer.py:536-572, is a
+ * Python loop over torch ops) -----------------------------------------------------------------------------------------
+ * One stream's piece of the train step is recorded ONCE by HIP stream capture (so launches that do not come from this
+ * library are recorded too) and re-issued per step from one C call: s2i_plan_create walks the captured hipGraph_t in
+ * dependency order and keeps every node's function, geometry and argument pointers; s2i_plan_replay issues them as plain
+ * launches on the given stream.  The caller keeps the captured graph (the argument storage belongs to it) and the memory
+ * pool the capture allocated from alive for as long as the plan is used.  Only kernel, 1-D memset and memcpy nodes
+ * are accepted; anything else fails with a message (the caller then falls back to the eager step).
+ * counts, if not NULL, receives [kernels, memsets, memcpys]. */
+int s2i_plan_create(void* hip_graph, void** plan_out, int* counts);
+int s2i_plan_replay(void* plan, void* stream);
+int s2i_plan_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

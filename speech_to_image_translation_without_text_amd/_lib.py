@@ -125,6 +125,9 @@ _SIGNATURES = {
     "s2i_ema_update": (c_int, [P, P, c_ll, c_float, P]),
     "s2i_scale_dev": (c_int, [P, P, c_ll, P, P]),
     "s2i_axpby": (c_int, [P, P, c_ll, c_float, c_float, P]),
+    "s2i_plan_create": (c_int, [P, ctypes.POINTER(P), ctypes.POINTER(c_int)]),
+    "s2i_plan_replay": (c_int, [P, P]),
+    "s2i_plan_destroy": (c_int, [P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -786,6 +786,7 @@ class ConvAct(torch.autograd.Function):
             out, _, _ = conv_raw(kind, x, None, packed, n_out, wR=packed.shape[1], ldw=packed.shape[2], bias=bias, act=act)
         ctx.save_for_backward(x, weight, out if act != ACT_NONE else None)
         ctx.kind_name, ctx.act, ctx.has_bias, ctx.n_out = kind_name, act, bias is not None, n_out
+        ctx.bias_ref = bias
         return out
 
     @staticmethod
@@ -813,7 +814,13 @@ class ConvAct(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             part = torch.empty((2, 1, N), dtype=torch.float32, device=dy.device)
             check(lib.s2i_colstats(ptr(cast(dy, torch.float32)), M, N, N, ptr(part), 1, stream()), "s2i_colstats")
-            db = part[0, 0, :weight.shape[0]].clone()
+            bias = ctx.bias_ref
+            O = weight.shape[0]
+            if _direct(bias):      # straight into the flat gradient buffer: no temporary, no AccumulateGrad add
+                check(lib.s2i_axpby(ptr(bias.grad), ptr(part), O, 1.0, 1.0, stream()), "s2i_axpby")
+            else:
+                db = torch.empty((O,), dtype=torch.float32, device=dy.device)
+                check(lib.s2i_axpby(ptr(db), ptr(part), O, 1.0, 0.0, stream()), "s2i_axpby")
         return dx, dw, db, None, None, None
 
 

@@ -255,14 +255,15 @@ class condGANTrainer(object):
             self.enable_graph()
 
     def _make_d_streams(self):
-        """One stream per discriminator; the largest one is the critical path of the step and gets the high priority,
-        so the smaller networks' kernels fill its gaps instead of delaying it (31.05 vs 31.35 ms / step).
-        The streams are shared by every trainer of the process: HIP maps streams onto a few hardware queues, and a second
-        trainer with three more streams of its own lost the overlap entirely (35.7 vs 20.7 ms / step, measured)."""
+        """One stream per discriminator, all at the default priority.  (Round 2 gave the largest discriminator's stream the
+        high HIP priority for 0.3 ms per step.  Round 3 found what that costs: while a high-priority queue holds PENDING
+        packets -- the next step's discriminator work waiting on an event -- every other queue's kernels run slower, so a
+        host that runs more than one step ahead made the step 20 % slower: 38.7 vs 31.6 ms, all of it in the generator's
+        single-stream pieces (tools/replay_pieces.py, profiles/r03_replay_regimes.txt).  That, not branch serialisation,
+        was also why hipGraph replay looked slow.)  The streams are shared by every trainer of the process."""
         key = (torch.cuda.current_device(), self.num_Ds)
         if key not in _D_STREAMS:
-            _D_STREAMS[key] = [torch.cuda.Stream(priority=-1 if i == self.num_Ds - 1 else 0)
-                               for i in range(self.num_Ds)]
+            _D_STREAMS[key] = [torch.cuda.Stream() for i in range(self.num_Ds)]
         return _D_STREAMS[key]
 
     # -- set-up -------------------------------------------------------------------------------------------
@@ -541,17 +542,21 @@ class condGANTrainer(object):
         return self._g_backward()
 
     # -- one iteration (trainer.py:536-572), Inception forwards excluded --------------------------------------------
-    def enable_graph(self, warmup=3):
-        """Replay the single-GPU step from hipGraphs after `warmup` eager steps.  The step is cut where its HIP streams
+    def enable_graph(self, warmup=3, executor="plan"):
+        """Replay the single-GPU step from a recording after `warmup` eager steps.  The step is cut where its HIP streams
         fork and join, and every piece is captured as a graph of ONE stream: the generator forward (main stream), per
         discriminator its update followed by its pass of the G update (that discriminator's stream), the generator's
         backward + Adam + EMA (main stream).  The pieces are launched like kernels -- stream waits between them -- so the
-        three discriminator streams stay concurrent (one graph of the whole step replays its forked branches one after
-        another on ROCm 7.2: DESIGN.md section 12).  Single process only: an RCCL all-reduce inside a captured graph is
+        three discriminator streams stay concurrent.  executor="plan" (default): the captured graphs are only the RECORDING;
+        their kernel nodes are re-issued as plain launches from one C call per piece (s2i_plan_replay, include/s2i_hip.h):
+        hipGraphLaunch itself is slower than the Python step it replaces on ROCm 7.2.
+        executor="graph": hipGraphLaunch of each piece.  Single process only: an RCCL all-reduce inside a recording is
         not exercised here."""
         # warm-up and capture run on one private stream: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and one that lives on the (non-capturing) default stream invalidates the capture
-        self._graph = dict(warmup=warmup, seen=0, graphs=None, stream=torch.cuda.Stream())
+        if executor not in ("plan", "graph"):
+            raise ValueError("executor must be 'plan' or 'graph'")
+        self._graph = dict(warmup=warmup, seen=0, graphs=None, stream=torch.cuda.Stream(), executor=executor)
 
     def _graph_signature(self, real_imgs, wrong_imgs, txt_embedding, noise, eps):
         ts = list(real_imgs) + list(wrong_imgs) + [txt_embedding, noise] + ([eps] if eps is not None else [])
@@ -577,7 +582,9 @@ class condGANTrainer(object):
         n = self.num_Ds
         # one memory pool per stream: pieces that replay concurrently must not share freed blocks
         pools = [torch.cuda.graph_pool_handle() for _ in range(n + 1)]
-        graphs = dict(fwd=torch.cuda.CUDAGraph(), d=[torch.cuda.CUDAGraph() for _ in range(n)], g=torch.cuda.CUDAGraph())
+        keep = st['executor'] == "plan"       # the plan reads the captured graph's nodes: keep the hipGraph_t
+        graphs = dict(fwd=torch.cuda.CUDAGraph(keep_graph=keep), d=[torch.cuda.CUDAGraph(keep_graph=keep) for _ in range(n)],
+                      g=torch.cuda.CUDAGraph(keep_graph=keep))
         errs = [None] * n
         with ops.param_grad_mode(True):
             with torch.cuda.graph(graphs['fwd'], pool=pools[n], stream=main):
@@ -596,7 +603,19 @@ class condGANTrainer(object):
                 outs = [o.detach().reshape(()) for o in (errD_total, errG_total, kl_loss)]
         for f in [self.flatG] + self.flatsD:
             f.step_count -= 1          # FlatNet.adam counted a step the capture did not execute; the replay below counts it
-        st.update(graphs=graphs, static=static, outs=outs, pools=pools,
+        plans = None
+        if keep:
+            import ctypes
+            from . import _lib
+            lib = _lib.load()
+
+            def make_plan(g):
+                handle, counts = ctypes.c_void_p(), (ctypes.c_int * 3)()
+                _lib.check(lib.s2i_plan_create(g.raw_cuda_graph(), ctypes.byref(handle), counts), "s2i_plan_create")
+                return handle, tuple(counts)
+            plans = dict(fwd=make_plan(graphs['fwd']), d=[make_plan(g) for g in graphs['d']], g=make_plan(graphs['g']))
+            st['launches'] = (plans['fwd'][1][0] + sum(p[1][0] for p in plans['d']) + plans['g'][1][0])
+        st.update(graphs=graphs, plans=plans, static=static, outs=outs, pools=pools,
                   sig=self._graph_signature(real_imgs, wrong_imgs, txt_embedding, noise, eps))
         # the capture itself did not execute anything: replay once so that this call IS a step
         return self._replay(real_imgs, wrong_imgs, txt_embedding, class_labels, noise, eps, fresh=True)
@@ -619,17 +638,29 @@ class condGANTrainer(object):
             if eps is not None:
                 put(s['eps'], eps)
             put(s['labels'], class_labels_to_device(class_labels, noise.device))
-        g = st['graphs']
         main = torch.cuda.current_stream()
-        g['fwd'].replay()
-        for i in reversed(range(self.num_Ds)):    # largest first, as the eager step enqueues them
-            side = self._side_streams[i]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                g['d'][i].replay()
-        for i in range(self.num_Ds):
-            main.wait_stream(self._side_streams[i])
-        g['g'].replay()
+        if st['plans'] is not None:
+            from . import _lib
+            lib, pl = _lib.load(), st['plans']
+            _lib.check(lib.s2i_plan_replay(pl['fwd'][0], main.cuda_stream), "s2i_plan_replay")
+            for i in reversed(range(self.num_Ds)):    # largest first, as the eager step enqueues them
+                side = self._side_streams[i]
+                side.wait_stream(main)
+                _lib.check(lib.s2i_plan_replay(pl['d'][i][0], side.cuda_stream), "s2i_plan_replay")
+            for i in range(self.num_Ds):
+                main.wait_stream(self._side_streams[i])
+            _lib.check(lib.s2i_plan_replay(pl['g'][0], main.cuda_stream), "s2i_plan_replay")
+        else:
+            g = st['graphs']
+            g['fwd'].replay()
+            for i in reversed(range(self.num_Ds)):
+                side = self._side_streams[i]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    g['d'][i].replay()
+            for i in range(self.num_Ds):
+                main.wait_stream(self._side_streams[i])
+            g['g'].replay()
         for f in [self.flatG] + self.flatsD:
             f.step_count += 1
         if txt_embedding.requires_grad and s['emb'].grad is not None:

@@ -21,3 +21,18 @@ def gpu():
     _lib.load()
     _lib.require_device()
     return torch.device("cuda:0")
+
+
+# The CPU oracle's convolutions (MKLDNN) sum in an order that depends on the intra-op thread count, and some tests compare
+# quantities that sit on LeakyReLU decisions (a 1e-7 change of a pre-activation can flip one).  One fixed thread count for
+# the whole session -- re-applied before every test, because the multi-process tests change it -- makes the oracle's
+# results independent of test order and of the box's core count.
+ORACLE_THREADS = 8
+
+
+@pytest.fixture(autouse=True)
+def _fixed_oracle_threads():
+    import torch
+    if torch.get_num_threads() != ORACLE_THREADS:
+        torch.set_num_threads(ORACLE_THREADS)
+    yield

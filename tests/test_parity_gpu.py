@@ -175,6 +175,70 @@ def test_discriminator_backward_explained_by_mask_flips(gpu):
         _d_only_backward_check(d, sd, SIZES[i], (batch['real'][i], batch['wrong'][i], fakes[i]), mu, gpu, "D%d init" % i)
 
 
+# ---- the same segment checks at FULL width (cfg/birds_3stages.yml channel counts; batch 8 keeps the CPU oracle at seconds) ----
+# At this width the backward launches the kernels that carry the benchmark: 128x128 and 96x128 tiles, split-K tails on the
+# 4x4 maps, the row-segment 3x3 weight gradient (wgrad_k3_rows_kernel<64,128>), the class-bias folded jointConv, thin / RGB
+# image layers -- none of which the reduced-width cases reach.
+FULL8 = dict(CASES['full3_fwd'], B=8)
+
+
+def test_generator_backward_elementwise_full_width(gpu):
+    """G alone at full width, fp32: every parameter gradient and grad_emb element-wise against the oracle, from the oracle's
+    dL/dfake_i (trainer.py:429-489 behind the images)."""
+    from oracle import stackgan_oracle as orc
+    netG, netsD = build_nets(FULL8)
+    batch = make_batch(FULL8)
+    ostate = orc.TrainState(netG.state_dict(), [d.state_dict() for d in netsD])
+    netG.to(gpu)
+    _g_only_backward_check(netG, ostate.g, ostate.ds, batch, oracle_dims(FULL8), gpu, "full width")
+
+
+def test_discriminator_backward_full_width_mask_replay(gpu):
+    """D alone at full width, fp32 (three separate passes, trainer.py:375-427): LeakyReLU decisions that differ from the
+    oracle's are counted, and the oracle's backward with the GPU's decisions agrees element-wise."""
+    from oracle import stackgan_oracle as orc
+    netG, netsD = build_nets(FULL8)
+    batch = make_batch(FULL8)
+    with torch.no_grad():
+        fakes, mu, _ = orc.g_forward({k: v.clone() for k, v in netG.state_dict().items()}, batch['noise'], batch['emb'],
+                                     batch['eps'], oracle_dims(FULL8))
+    for i, d in enumerate(netsD):
+        sd = {k: v.clone() for k, v in d.state_dict().items()}
+        d.to(gpu)
+        _d_only_backward_check(d, sd, SIZES[i], (batch['real'][i], batch['wrong'][i], fakes[i]), mu, gpu, "D%d full width" % i)
+        d.cpu()
+
+
+def test_stacked_discriminator_update_full_width_equals_separate_passes(gpu):
+    """The trainer's stacked real / wrong / fake pass (BatchNorm groups = 3, ONE weight-gradient GEMM over the three batches,
+    96-row tiles on the 72-image launches' little brothers here) against three separate passes at full width: the flat
+    parameter gradients of every discriminator agree norm-wise (a handful of LeakyReLU decisions may fall the other way:
+    the per-batch statistics are summed in another order)."""
+    from speech_to_image_translation_without_text_amd import trainer as T
+    netG, netsD = build_nets(FULL8)
+    batch = make_batch(FULL8)
+    grads = []
+    for stacked in (True, False):
+        g2, ds2 = copy.deepcopy(netG).to(gpu), [copy.deepcopy(d).to(gpu) for d in netsD]
+        tr = T.condGANTrainer(None, None, 256, False)
+        tr.build(g2, ds2)
+        tr.stack_d_passes = stacked
+        for f in tr.flatsD:
+            f.lr = 0.0
+        b = to_dev(batch, gpu)
+        tr._begin_step(b['real'], b['wrong'], b['emb'], batch['labels'])
+        with torch.no_grad():
+            tr.fake_imgs, tr.mu, tr.logvar = g2(b['noise'], b['emb'], b['eps'])
+        from speech_to_image_translation_without_text_amd import ops
+        with ops.param_grad_mode(True):
+            errs = [float(tr.train_Dnet(i, 0)) for i in range(3)]
+        torch.cuda.synchronize()
+        grads.append((errs, [f.g.detach().cpu().clone() for f in tr.flatsD]))
+    for i in range(3):
+        assert abs(grads[0][0][i] - grads[1][0][i]) <= 1e-5 * abs(grads[1][0][i]), (i, grads[0][0][i], grads[1][0][i])
+        assert_close_l2(grads[0][1][i], grads[1][1][i], 2e-3, what="D%d stacked vs separate flat gradient" % i)
+
+
 def _export_state(tr, netG, netsD):
     """HIP trainer state -> oracle TrainState (weights, BatchNorm buffers, Adam moments and step counts, EMA)."""
     from oracle import stackgan_oracle as orc
@@ -481,15 +545,18 @@ def test_ragged_batch_full_train_step(gpu, B):
     assert_close(float(errD), oout['errD_total'], rtol=1e-3, atol=1e-4, what="errD_total B=%d" % B)
     assert_close(float(errG), oout['errG_total'], rtol=1e-3, atol=1e-4, what="errG_total B=%d" % B)
     # G's gradients pass the discriminators' LeakyReLU chains on the fake images: a single decision that differs from the
-    # oracle's moves them by ~1e-2 in norm at these small batches (measured: 5e-6 with no differing decision, 1.5e-3 .. 3.9e-2
-    # with a few -- which ones differ changes with what ran before in the process on the ORACLE's side (CPU thread count
-    # after the multi-process tests); the HIP step itself is bitwise independent of allocator history at these batches,
-    # tools/ragged_probe.py).  The element-wise bounds are held by the segmented tests above; this bound only catches a
-    # wrong ragged-batch code path (a dropped or doubled sample is >= 2e-1 at B = 5).
-    assert_close_l2(emb.grad, oout['grad_emb'], 1e-1, what="grad_emb B=%d" % B)
+    # oracle's moves them by ~1e-2 in norm at these small batches (5e-6 with no differing decision).  The oracle runs at a
+    # fixed thread count (conftest.py), so which decisions differ no longer depends on what ran before; the element-wise
+    # bounds are held by the segmented tests above, this bound catches a wrong ragged-batch code path (a dropped or doubled
+    # sample is >= 2e-1 at B = 5).
+    worst = float((emb.grad.cpu().double() - oout['grad_emb'].double()).norm() / oout['grad_emb'].double().norm())
     named = dict(netG.named_parameters())
     for k, g in oout['grad_g'].items():
-        assert_close_l2(named[k].grad.cpu(), g, 1e-1, what="dG/%s B=%d" % (k, B))
+        worst = max(worst, float((named[k].grad.cpu().double() - g.double()).norm() / (g.double().norm() + 1e-30)))
+    print("ragged batch B=%d: worst relative L2 deviation of a G gradient %.2e" % (B, worst))
+    assert_close_l2(emb.grad, oout['grad_emb'], 2e-2, what="grad_emb B=%d" % B)
+    for k, g in oout['grad_g'].items():
+        assert_close_l2(named[k].grad.cpu(), g, 2e-2, what="dG/%s B=%d" % (k, B))
 
 
 def test_step_scopes_the_direct_gradient_switches(gpu):

@@ -34,6 +34,11 @@ def main():
     emb = torch.randn(B, 1024, device=dev, generator=g)
     labels = (torch.arange(B, device=dev) % 3).to(torch.int32)
     noise = torch.randn(B, 100, device=dev, generator=g); eps = torch.randn(B, 128, device=dev, generator=g)
+    # optional third argument "side": run the main-stream work on a created stream instead of the default (null) stream
+    if len(sys.argv) > 3 and sys.argv[3] == "side":
+        main_ctx = torch.cuda.stream(torch.cuda.Stream())
+        main_ctx.__enter__()
+        print("main stream: a created stream")
     for _ in range(3):
         tr.train_step(real, wrong, emb.detach().requires_grad_(True), labels, noise, eps)
     torch.cuda.synchronize()
