@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define S2I_ABI_VERSION 3
+#define S2I_ABI_VERSION 4
 
 /* conv geometry kinds */
 #define S2I_CONV_K1      0  /* 1x1 / nn.Linear (model.py:179, 217)                              */
@@ -86,6 +86,9 @@ typedef struct s2i_conv_desc {
   int kw, stride, pad; /* S2I_CONV_1D geometry (ignored by the other kinds)                       */
   int tile_rows; /* output rows per block of the fp32 matrix kernel: 0 = the planner chooses (96 or 128, whichever
                     fills whole rounds of the chip's block slots); 96 or 128 forces it (96 only where N > 64)     */
+  int in_act;    /* s2i_conv_forward_in only: activation of the PRODUCING block applied to x while it is gathered
+                    (S2I_ACT_LRELU); 0 elsewhere                                                              */
+  int in_groups; /* ... and the number of BatchNorm groups of its coefficient table (0 or 1 = one)               */
 } s2i_conv_desc;
 
 /* scratch bytes s2i_conv_forward needs for this descriptor (split-K slabs; 0 when not split) */
@@ -106,6 +109,15 @@ int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const float* cvec, 
 int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                          const float* bias, const float* cls_bias, float* y, float* part, void* ws,
                          size_t ws_bytes, void* stream);
+
+/* Apply-on-load ("BatchNorm + LeakyReLU fused into the consuming convolution", model.py:369-376 followed by :371 / :360
+   of the next block): x_raw is the RAW output y of the producing convolution and in_coef its (in_groups, 4, Cx)
+   coefficient table [mean, invstd, scale, shift] (s2i_bn_finalize); the gather computes
+   LeakyReLU(scale * y + shift) while it stages the operand, padding taps staying zero, so the producer's activated tensor
+   is never written or read.  fp32, forward weight layout (wmode 0), 32 | Cx, no broadcast vector, kinds K1 / K3S1 / K4S2;
+   with in_groups > 1 the rows of one producer group must be whole row tiles (as for `groups`). */
+int s2i_conv_forward_in(const s2i_conv_desc* d, const float* x_raw, const float* in_coef, const float* w, float* y,
+                        float* part, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- spatially constant channels of a 3x3 conv (c_code broadcast, model.py:272-279) -----------
  * A channel that is constant over space contributes sum over the IN-BOUNDS taps of c*W: a bias that
@@ -138,6 +150,8 @@ typedef struct s2i_wgrad_desc {
   int accumulate;   /* 1: grad += result, 0: grad = result                                      */
   int i_off;        /* the I input channels computed here are channels [i_off, i_off+I) of a       */
   int I_total;      /* parameter with I_total input channels (0 = I): the c_code / h_code split    */
+  int a_act;        /* s2i_conv_wgrad_in only: activation of the block that produced `a` (S2I_ACT_LRELU)    */
+  int a_groups;     /* ... and the BatchNorm groups of its coefficient table (0 or 1 = one; at most 3)      */
 } s2i_wgrad_desc;
 
 size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);
@@ -148,6 +162,14 @@ size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d);
  */
 int s2i_conv_wgrad(const s2i_wgrad_desc* d, const float* a, const float* cvec, const float* g,
                    float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+
+/* The weight gradient of the same consumer: the gathered operand is the producer's RAW output a_raw with its coefficient
+   table, activated while it is staged (s2i_conv_forward_in).  Only where s2i_conv_wgrad_in_eligible(d) says so (the
+   generic fp32 128 x 128 plan: every layer of the discriminator towers); otherwise the caller materialises the operand. */
+int s2i_conv_wgrad_in_eligible(const s2i_wgrad_desc* d);
+int s2i_conv_wgrad_in(const s2i_wgrad_desc* d, const float* a_raw, const float* a_coef, const float* g,
+                      float* grad_oihw, void* ws, size_t ws_bytes, void* stream);
+
 
 /* ---- split-bf16 matrix products (1 / 2 / 3 bf16 planes; opt-in) ---------------------
  * Same convolution as s2i_conv_forward_cls, with every fp32 operand written as a sum of `planes` bf16 numbers and the

@@ -17,7 +17,7 @@ CONV_K1, CONV_K3S1, CONV_K4S2, TCONV_K4S2, CONV_1D = 0, 1, 2, 3, 4
 ACT_NONE, ACT_GLU, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3, 4
 PACK_PLAIN, PACK_UPFOLD = 0, 1
 DT_F32, DT_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_longlong)
@@ -26,12 +26,12 @@ c_int, c_float, c_void_p, c_size_t, c_ll = (ctypes.c_int, ctypes.c_float, ctypes
 class ConvDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Cx", "Cc", "N", "wmode", "flip", "wR",
                                      "ldw", "act", "stats", "ldy", "groups", "nosplit", "kw", "stride", "pad",
-                                     "tile_rows")]
+                                     "tile_rows", "in_act", "in_groups")]
 
 
 class WgradDesc(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("kind", "B", "H", "W", "Ca", "Cc", "N", "ldg", "swap", "fold",
-                                     "O", "I", "KH", "KW", "accumulate", "i_off", "I_total")]
+                                     "O", "I", "KH", "KW", "accumulate", "i_off", "I_total", "a_act", "a_groups")]
 
 
 class PackItem(ctypes.Structure):
@@ -55,6 +55,9 @@ _SIGNATURES = {
     "s2i_conv_stat_parts": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_forward": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, c_size_t, P]),
     "s2i_conv_forward_cls": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, P, P, c_size_t, P]),
+    "s2i_conv_forward_in": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, P, P, P, c_size_t, P]),
+    "s2i_conv_wgrad_in_eligible": (c_int, [ctypes.POINTER(WgradDesc)]),
+    "s2i_conv_wgrad_in": (c_int, [ctypes.POINTER(WgradDesc), P, P, P, P, P, c_size_t, P]),
     "s2i_conv_split_eligible": (c_int, [ctypes.POINTER(ConvDesc)]),
     "s2i_conv_forward_split": (c_int, [ctypes.POINTER(ConvDesc), P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "s2i_split_packed_weight": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P]),

@@ -44,6 +44,10 @@ struct IgemmP {
   const unsigned short* __restrict__ wsp;
   int wsp_np, wsp_kp, wsp_plane;  // rows per tap, row length (bf16 elements), elements per plane
   unsigned wsp_bytes;
+  // apply-on-load (INACT instantiations): x holds the RAW output of the producing convolution; the gather applies that
+  // layer's BatchNorm (scale, shift from its (groups, 4, Cx) coefficient table) and LeakyReLU while it stages the operand
+  const float* __restrict__ in_coef;
+  int in_rows_per_group;   // output rows of THIS launch per BatchNorm group of the producer (rows beyond: next group)
 };
 
 __device__ __forceinline__ void geom(const IgemmP& p, int kind, int& s, int& pad, int& kw) {
@@ -169,8 +173,10 @@ __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_c
 // Measured alternatives that lost (MI355X, 64->128 k4s2 on 24x128x128): two LDS stages with one barrier per
 // chunk (2 blocks/CU: 79 vs 98 TFLOP/s), a start-up stagger of the blocks (no change).  Three resident blocks
 // per CU with the plain two-barrier loop is the fastest structure found for v_mfma_f32_32x32x2_f32.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT, bool CA32>
+// INACT (CA32, no broadcast vector, forward weights only): see IgemmP::in_coef.  Padding taps stay zero AFTER the activation.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool WT, bool CA32, bool INACT = false>
 __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
+  static_assert(!INACT || (CA32 && !WT), "apply-on-load: 32-channel chunks, forward weight layout");
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM + 1;
   constexpr int LDB = WT ? BN + 1 : BN;
@@ -237,6 +243,11 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
   }
 
   f32x4 ra[ASLOTS], rb[BSLOTS];
+  // apply-on-load state of the chunk held in ra: scale / shift of this thread's four channels and the chunk's tap
+  f32x4 in_s = {1.f, 1.f, 1.f, 1.f}, in_t = {0.f, 0.f, 0.f, 0.f};
+  int in_tap = 0;
+  const float* in_cg = nullptr;
+  if constexpr (INACT) in_cg = p.in_coef + (size_t)(m0 / p.in_rows_per_group) * 4 * p.Cx;   // a tile lies inside one group
 
   auto fetch = [&](int kc) {
     if (CA32) {
@@ -247,6 +258,11 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
       int dy, dx;
       tap_delta(p.kind, kw, t, py, px, dy, dx);
       const int tw = tap_weight(p.kind, p.flip, p.T, t, py, px);
+      if constexpr (INACT) {
+        in_tap = t;
+        in_s = *reinterpret_cast<const f32x4*>(in_cg + 2 * p.Cx + c0 + kq * 4);
+        in_t = *reinterpret_cast<const f32x4*>(in_cg + 3 * p.Cx + c0 + kq * 4);
+      }
       if (c0 < p.Cc) {
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i)
@@ -315,7 +331,15 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Asd[(kq * 4 + j) * LDA + mrow + 32 * i] = ra[i][j];
+      for (int j = 0; j < 4; ++j) {
+        float v = ra[i][j];
+        if constexpr (INACT) {
+          v = fmaf(v, in_s[j], in_t[j]);
+          v = v > 0.f ? v : 0.2f * v;
+          v = ((amask[i] >> in_tap) & 1u) ? v : 0.f;      // the padding is zero in the ACTIVATED tensor
+        }
+        Asd[(kq * 4 + j) * LDA + mrow + 32 * i] = v;
+      }
     if (WT) {
 #pragma unroll
       for (int i = 0; i < BSLOTS; ++i)
@@ -1233,9 +1257,13 @@ struct WgradP {
   int cps, nchunks;
   int a16, g16;  // a / g hold bf16 instead of fp32
   unsigned a_bytes, c_bytes, g_bytes;
+  // apply-on-load (AACT instantiation): `a` holds the RAW output of the producing convolution, a_coef its (groups, 4, Ca)
+  // BatchNorm coefficient table; the gather computes LeakyReLU(scale * a + shift), padding taps staying zero
+  const float* __restrict__ a_coef;
+  int a_groups, a_ipg;   // BatchNorm groups of the producer, images per group
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool AACT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM, LDB = BN;
@@ -1276,7 +1304,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
   const int ccolb = c * 4;                     // ... inside a row of cvec
   const int gcolb = nvalid ? nb * 4 : S2I_OOB;
   f32x4 ra[APASS], rb[BPASS];
+  // apply-on-load: this thread's four channels are the same for the whole pixel loop, so their scale / shift (per producer
+  // group: at most three, the stacked real / wrong / fake passes) sit in registers; per pass, which group the pixel's image
+  // belongs to (2 bits) and whether the tap is inside the image (1 bit)
+  f32x4 gs[3], gt[3];
+  unsigned apass = 0;
+  if constexpr (AACT) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int gg = g < p.a_groups ? g : 0;
+      gs[g] = kvalid ? *reinterpret_cast<const f32x4*>(p.a_coef + ((size_t)gg * 4 + 2) * p.Ca + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      gt[g] = kvalid ? *reinterpret_cast<const f32x4*>(p.a_coef + ((size_t)gg * 4 + 3) * p.Ca + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   auto fetch = [&](int pc) {
+    if constexpr (AACT) apass = 0;
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
       const int m = pc * 32 + arow + q * AROWS;
@@ -1286,6 +1328,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
       const int oy = r >> p.lgWo, ox = r & (p.Wo - 1);
       const int iy = oy * s - pad + dy, ix = ox * s - pad + dx;
       const bool ok = kvalid && m < p.M && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      if constexpr (AACT) {
+        const unsigned grp = (unsigned)(b >= p.a_ipg) + (unsigned)(b >= 2 * p.a_ipg);
+        apass |= ((ok ? 4u : 0u) | grp) << (3 * q);
+      }
       if (from_vec) ra[q] = bload4(rc_rs, ok ? b * p.Cc * 4 + ccolb : S2I_OOB);
       else ra[q] = bload4_any(ra_rs, ok ? ((b * p.H + iy) * p.W + ix) * p.Ca * 4 + acolb : S2I_OOB, p.a16);
     }
@@ -1311,7 +1357,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
   for (int pc = c_begin; pc < c_end; ++pc) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q)
-      if (!APRED || arow + q * AROWS < 32) *reinterpret_cast<f32x4*>(As + (arow + q * AROWS) * LDA + acol4 * 4) = ra[q];
+      if (!APRED || arow + q * AROWS < 32) {
+        f32x4 v = ra[q];
+        if constexpr (AACT) {
+          const unsigned bits = (apass >> (3 * q)) & 7u;
+          const unsigned grp = bits & 3u;
+          const f32x4 sc = grp == 0 ? gs[0] : (grp == 1 ? gs[1] : gs[2]);
+          const f32x4 sh = grp == 0 ? gt[0] : (grp == 1 ? gt[1] : gt[2]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float z = fmaf(v[j], sc[j], sh[j]);
+            z = z > 0.f ? z : 0.2f * z;
+            v[j] = (bits & 4u) ? z : 0.f;
+          }
+        }
+        *reinterpret_cast<f32x4*>(As + (arow + q * AROWS) * LDA + acol4 * 4) = v;
+      }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q)
       if (!BPRED || brow + q * BROWS < 32) *reinterpret_cast<f32x4*>(Bs + (brow + q * BROWS) * LDB + bcol4 * 4) = rb[q];
@@ -2188,6 +2249,10 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_fwd(const IgemmP& p, dim3 grid, bool wt, bool ca32, hipStream_t st) {
+  if (p.in_coef) {   // apply-on-load (conv_forward_impl admits it for !wt && ca32 only)
+    hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, false, true, true>), grid, dim3(256), 0, st, p);
+    return;
+  }
   if (wt) {
     if (ca32) hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_fwd_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, p);
@@ -2274,13 +2339,19 @@ extern "C" int s2i_conv_forward(const s2i_conv_desc* d, const float* x, const fl
 static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                              const unsigned short* wsp, int planes, int np, int kp, const float* bias,
                              const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream,
-                             int x16 = 0, int y16 = 0);
+                             int x16 = 0, int y16 = 0, const float* in_coef = nullptr);
 
 extern "C" int s2i_conv_forward_cls(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                                     const float* bias, const float* cls_bias, float* y, float* part, void* ws,
                                     size_t ws_bytes, void* stream) {
   S2I_REQUIRE(w != nullptr, "conv: null weight");
   return conv_forward_impl(d, x, cvec, w, nullptr, 0, 0, 0, bias, cls_bias, y, part, ws, ws_bytes, stream);
+}
+
+extern "C" int s2i_conv_forward_in(const s2i_conv_desc* d, const float* x_raw, const float* in_coef, const float* w, float* y,
+                                   float* part, void* ws, size_t ws_bytes, void* stream) {
+  S2I_REQUIRE(w != nullptr && in_coef != nullptr, "conv(apply-on-load): null weight / coefficient table");
+  return conv_forward_impl(d, x_raw, nullptr, w, nullptr, 0, 0, 0, nullptr, nullptr, y, part, ws, ws_bytes, stream, 0, 0, in_coef);
 }
 
 extern "C" int s2i_conv_split_eligible(const s2i_conv_desc* d) {
@@ -2332,7 +2403,7 @@ extern "C" int s2i_conv_forward_dt(const s2i_conv_desc* d, const void* x, int x_
 static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float* cvec, const float* w,
                              const unsigned short* wsp, int planes, int np, int kp, const float* bias,
                              const float* cls_bias, float* y, float* part, void* ws, size_t ws_bytes, void* stream,
-                             int x16, int y16) {
+                             int x16, int y16, const float* in_coef) {
   FwdPlan pl;
   if (plan_fwd(d, &pl)) return 1;
   S2I_REQUIRE(!cls_bias || (d->kind == S2I_CONV_K3S1 && pl.splitk == 1), "conv: class bias needs an unsplit 3x3 conv");
@@ -2357,7 +2428,18 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
   S2I_REQUIRE(!(wsp && (x16 || y16)), "conv(split): bf16 tensors go through s2i_conv_forward_bf16 / _dt");
   S2I_REQUIRE(!wsp || pl.bm == 128, "conv(split): the split-bf16 kernels have 128-row tiles (set tile_rows = 128)");
   p.wsp = wsp; p.wsp_np = np; p.wsp_kp = kp; p.wsp_plane = 0; p.wsp_bytes = 0;
-  const int rk = (!wsp && !cls_bias) ? rgb_kind(d, pl, x16, y16) : 0;
+  p.in_coef = in_coef; p.in_rows_per_group = pl.M;
+  if (in_coef) {
+    const int g = d->in_groups < 1 ? 1 : d->in_groups;
+    S2I_REQUIRE(d->in_act == S2I_ACT_LRELU, "conv(apply-on-load): the producer's activation must be LeakyReLU (in_act=%d)", d->in_act);
+    S2I_REQUIRE(!wsp && !x16 && !y16 && d->Cc == 0 && d->wmode == 0 && (pl.Ca % 32) == 0 && d->N > 4 && !bias && !cls_bias &&
+                    d->kind != S2I_CONV_1D && d->kind != S2I_TCONV_K4S2,
+                "conv(apply-on-load): fp32 forward of a stored tensor with 32 | Cx, no broadcast vector / bias");
+    S2I_REQUIRE((pl.M % g) == 0 && (g == 1 || ((pl.M / g) % pl.bm) == 0),
+                "conv(apply-on-load): %d rows do not split into %d producer groups of whole %d-row tiles", pl.M, g, pl.bm);
+    p.in_rows_per_group = pl.M / g;
+  }
+  const int rk = (!wsp && !cls_bias && !in_coef) ? rgb_kind(d, pl, x16, y16) : 0;
   if (rk && ws && ws_bytes >= rgb_afrag_elems(d, pl, rk) * 2 && !(rk == 2 && bias)) {
     unsigned short* afrag = (unsigned short*)ws;
     const int total = (int)rgb_afrag_elems(d, pl, rk);
@@ -2387,7 +2469,7 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     S2I_LAUNCH_CHECK("rgb_conv");
     return 0;
   }
-  const int tk = (!wsp && !cls_bias) ? thin_kind(d, pl) : 0;
+  const int tk = (!wsp && !cls_bias && !in_coef) ? thin_kind(d, pl) : 0;
   if (tk && ws && ws_bytes >= thin_table_floats(d, pl, tk) * sizeof(float)) {
     p.wt = d->wmode != 0;
     float* table = (float*)ws;
@@ -2484,7 +2566,27 @@ extern "C" size_t s2i_wgrad_workspace_bytes(const s2i_wgrad_desc* d) {
 }
 
 static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
-                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16 = 0, int g16 = 0);
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16 = 0, int g16 = 0,
+                           const float* a_coef = nullptr);
+
+// apply-on-load weight gradient: the generic 128 x 128 fp32 kernel only (the discriminator towers' layers)
+static bool wgrad_in_ok(const s2i_wgrad_desc* d, const WgPlan& pl) {
+  const int g = d->a_groups < 1 ? 1 : d->a_groups;
+  return d->a_act == S2I_ACT_LRELU && d->Cc == 0 && !d->swap && !pl.rows3 && !pl.small_n && pl.tile == 0 && g <= 3 &&
+         (d->B % g) == 0;
+}
+
+extern "C" int s2i_conv_wgrad_in_eligible(const s2i_wgrad_desc* d) {
+  WgPlan pl;
+  if (plan_wgrad(d, &pl)) return 0;
+  return wgrad_in_ok(d, pl) ? 1 : 0;
+}
+
+extern "C" int s2i_conv_wgrad_in(const s2i_wgrad_desc* d, const float* a_raw, const float* a_coef, const float* g,
+                                 float* grad_oihw, void* ws, size_t ws_bytes, void* stream) {
+  S2I_REQUIRE(a_coef != nullptr, "wgrad(apply-on-load): null coefficient table");
+  return conv_wgrad_impl(d, 0, a_raw, nullptr, g, grad_oihw, ws, ws_bytes, stream, 0, 0, a_coef);
+}
 
 extern "C" size_t s2i_wgrad_workspace_bytes_dt(const s2i_wgrad_desc* d, int a_dtype, int g_dtype) {
   WgPlan pl;
@@ -2525,7 +2627,7 @@ static void launch_wgrad_split(const WgradP& p, dim3 grid, int planes, hipStream
 }
 
 static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, const float* cvec, const float* g,
-                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16, int g16) {
+                           float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16, int g16, const float* a_coef) {
   WgPlan pl;
   // bf16 operands: the plan of the split modes (no row-segment / 96-row tiles, which stage fp32 rows)
   if (plan_wgrad(d, &pl, (planes || a16 || g16) ? 1 : 0)) return 1;
@@ -2543,6 +2645,12 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
   p.M = pl.M; p.N = d->N; p.ldg = d->ldg; p.K = pl.K; p.T = pl.T; p.kind = d->kind;
   p.cps = pl.cps; p.nchunks = pl.nchunks;
   p.a16 = a16; p.g16 = g16;
+  p.a_coef = a_coef; p.a_groups = d->a_groups < 1 ? 1 : d->a_groups; p.a_ipg = d->B / p.a_groups;
+  if (a_coef) {
+    S2I_REQUIRE(!planes && !a16 && !g16 && wgrad_in_ok(d, pl),
+                "wgrad(apply-on-load): fp32 operands, LeakyReLU producer, no broadcast vector, 128 x 128 tile plan (check "
+                "s2i_conv_wgrad_in_eligible)");
+  }
   {
     const unsigned long long ab = (unsigned long long)d->B * d->H * d->W * d->Ca * (a16 ? 2ull : 4ull);
     const unsigned long long gb = (unsigned long long)pl.M * d->ldg * (g16 ? 2ull : 4ull);
@@ -2590,7 +2698,8 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(small_n_wgrad_kernel<16>, dim3(pl.splitk), dim3(256), 0, st, p);
-  } else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
+  } else if (pl.tile == 0 && a_coef) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
+  else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 3) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 2, 2>), grid, dim3(256), 0, st, p);

@@ -49,10 +49,12 @@ class _Fused(nn.Sequential):
     conv_at = 0
     bn_at = 1
 
-    def forward(self, x, cvec=None, residual=None, groups=1):
+    def forward(self, x, cvec=None, residual=None, groups=1, defer=False):
+        """defer=True: the caller hands the result to exactly ONE further convolution block, which may gather this block's
+        raw conv output and apply BatchNorm + LeakyReLU while it loads (ops.py, "apply-on-load")."""
         conv, bn = self[self.conv_at], self[self.bn_at]
         return ops.ConvBnAct.apply(x, cvec, conv.weight, bn.weight, bn.bias, residual, self.kind, self.act,
-                                   _bn_state(bn), self.training, groups)
+                                   _bn_state(bn), self.training, groups, defer)
 
 
 class UpBlock(_Fused):
@@ -131,14 +133,17 @@ class EncodeImageBy16(nn.Sequential):
                        nn.LeakyReLU(0.2, inplace=False)]
         super().__init__(*layers)
 
-    def forward(self, x, groups=1, taps=None):
+    def forward(self, x, groups=1, taps=None, defer_last=False):
+        """defer_last: the result goes to exactly one further convolution block (the deeper discriminators' towers)."""
         h = ops.ConvAct.apply(x, self[0].weight, None, "k4s2", ACT_LRELU, self[0].out_channels)
         if taps is not None:
             taps.append(h)
         for ci in (2, 5, 8):
             bn = self[ci + 1]
+            # inside the chain every block feeds only the next one: BatchNorm + LeakyReLU are applied by that block's gather
+            defer = taps is None and (ci != 8 or defer_last)
             h = ops.ConvBnAct.apply(h, None, self[ci].weight, bn.weight, bn.bias, None, "k4s2", ACT_LRELU,
-                                    _bn_state(bn), self.training, groups)
+                                    _bn_state(bn), self.training, groups, defer)
             if taps is not None:
                 taps.append(h)
         return h
@@ -326,15 +331,16 @@ class _DNet(nn.Module):
         every BatchNorm keeps separate statistics per batch, updating its running statistics in that order.
         `taps` (a list, tests only) receives the NHWC output of every LeakyReLU block in forward order."""
         x = ops.ToNHWC.apply(x_var, 4)
-        x_code = self.img_code_s16(x, groups, taps)
+        x_code = self.img_code_s16(x, groups, taps, defer_last=bool(self._tower))
         hook = getattr(self, 'after_s16_hook', None)
         if hook is not None and x_code.requires_grad:
             # fires when the gradient of img_code_s16's output exists, i.e. when the parameter gradients of the tower and
             # the heads (96 % of D_NET256's parameters) have been issued: the data-parallel trainer starts reducing that
             # part of the flat gradient there, under the backward of the four image-side convolutions
             x_code.register_hook(hook)
-        for name in self._tower:
-            x_code = getattr(self, name)(x_code, groups=groups)
+        for k, name in enumerate(self._tower):
+            # every tower block but the last feeds only the next block (the last one's map goes to three consumers)
+            x_code = getattr(self, name)(x_code, groups=groups, defer=taps is None and k + 1 < len(self._tower))
             if taps is not None:
                 taps.append(x_code)
         B, C = x_code.shape[0], x_code.shape[3]

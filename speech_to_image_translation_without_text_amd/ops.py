@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (ACT_GLU, ACT_NONE, CONV_K1, CONV_K3S1, CONV_K4S2, DT_BF16, DT_F32,
+from ._lib import (ACT_GLU, ACT_LRELU, ACT_NONE, CONV_K1, CONV_K3S1, CONV_K4S2, DT_BF16, DT_F32,
                    PACK_PLAIN, PACK_UPFOLD, TCONV_K4S2, ConvDesc, WgradDesc, check, ptr, stream)
 
 BN_EPS = 1e-5
@@ -422,8 +422,49 @@ def _geom(kind, H, W):
 TILE_ROWS = 0
 
 
+# ---- deferred BatchNorm + activation ("apply-on-load") ------------------------------------------------------------------
+# A block whose ONLY consumer is the next convolution can skip its normalise + LeakyReLU pass: ConvBnAct(..., defer=True)
+# returns its activated tensor UNWRITTEN, tagged with the raw conv output y and the coefficient table; a consuming
+# ConvBnAct gathers y through s2i_conv_forward_in (and s2i_conv_wgrad_in in its backward), which apply scale / shift /
+# LeakyReLU while they stage the operand -- the activated tensor is never written or read.  Anything else that touches a
+# tagged tensor goes through real(), which runs the skipped pass into the tensor's storage first.  Callers opt in per block
+# (model.py: the discriminator towers' chains); fp32 tensors, LeakyReLU, training mode.
+# MEASURED (round 3, one MI355X, batch 24): bit-for-rounding equal to the separate pass (tests/test_parity_gpu.py::
+# test_apply_on_load_equals_the_separate_activation_pass) and SLOWER: 32.5 vs 31.65 ms per step.  The fp32 matrix kernels
+# are bound by the matrix pipe, and an im2col gather sees every input element once per TAP: the fma + LeakyReLU + padding
+# select run 9 - 16 times per element in the staging path between two barriers, which costs the 36 fused launches more
+# (+7 %) than the 49 removed passes took (0.35 ms of HBM-bound kernels that overlapped other streams anyway).  Off by default
+# (S2I_DEFER_ACT=1 turns it on); DESIGN.md section 13 has the byte accounting for the other block types.
+DEFER_ACT = os.environ.get("S2I_DEFER_ACT", "0") == "1"
+
+
+class _Lazy:
+    __slots__ = ("y", "coef", "act", "groups", "done")
+
+    def __init__(self, y, coef, act, groups):
+        self.y, self.coef, self.act, self.groups, self.done = y, coef, act, groups, False
+
+
+def real(x):
+    """The tensor with its deferred BatchNorm + activation pass executed (no-op for ordinary tensors)."""
+    lz = getattr(x, '_s2i_lazy', None)
+    if lz is not None and not lz.done:
+        lib = _lib_ready()
+        C = lz.y.shape[-1]
+        M = lz.y.numel() // C
+        check(lib.s2i_bn_act_forward_dt(_dt(lz.y), ptr(lz.y), M, lz.groups, C, ptr(lz.coef), lz.act, None, ptr(x),
+                                        stream()), "s2i_bn_act_forward")
+        lz.done = True
+    return x
+
+
+def _pending(x):
+    lz = getattr(x, '_s2i_lazy', None)
+    return lz if (lz is not None and not lz.done) else None
+
+
 def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, act=ACT_NONE, stats=False, groups=1,
-             w_offset=0, cls_bias=None, conv1d=None):
+             w_offset=0, cls_bias=None, conv1d=None, in_src=None):
     """x: [B,H,W,Cx] contiguous NHWC.  Returns (y [B,Ho,Wo,N], part or None, nparts).
     w_offset (floats) skips leading weight rows (the c_code rows of a jointConv); cls_bias [B][9][N]
     adds their pre-reduced contribution per border class."""
@@ -435,7 +476,8 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
     if conv1d is not None:
         Ho, Wo = H, (W + 2 * pd1 - kw1) // st1 + 1
     d = ConvDesc(kind, B, H, W, Cx, Cc, N, wmode, flip, wR, ldw, act, 1 if stats else 0, N, groups,
-                 1 if cls_bias is not None else 0, kw1, st1, pd1, 128 if MATH_PLANES else TILE_ROWS)
+                 1 if cls_bias is not None else 0, kw1, st1, pd1, 128 if MATH_PLANES else TILE_ROWS,
+                 in_src.act if in_src is not None else 0, in_src.groups if in_src is not None else 0)
     y = torch.empty((B, Ho, Wo, N), dtype=torch.float32, device=x.device)
     if EXEC_LOG is not None:
         T = kw1 if conv1d is not None else _TAPS[kind]
@@ -450,8 +492,8 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
         part = torch.empty((2, nparts, N), dtype=torch.float32, device=x.device)
     wsb = lib.s2i_conv_workspace_bytes(ctypes.byref(d))
     ws = _ws.get(wsb, x.device)
-    if (MATH_PLANES and w_offset == 0 and packed.dim() == 3 and getattr(packed, '_s2i_gen', None) is not None
-            and lib.s2i_conv_split_eligible(ctypes.byref(d))):
+    if (MATH_PLANES and in_src is None and w_offset == 0 and packed.dim() == 3
+            and getattr(packed, '_s2i_gen', None) is not None and lib.s2i_conv_split_eligible(ctypes.byref(d))):
         transpose = wmode == 0
         np_, kp = (packed.shape[2], packed.shape[1]) if transpose else (packed.shape[1], packed.shape[2])
         if kp % 8 == 0:
@@ -461,12 +503,17 @@ def conv_raw(kind, x, cvec, packed, N, *, wmode=0, flip=0, wR, ldw, bias=None, a
                   "s2i_conv_forward_split")
             return y, part, nparts
     wp = ptr(packed) + 4 * int(w_offset)
+    if in_src is not None:
+        # x is the raw output of the producing block: its BatchNorm + LeakyReLU are applied while the operand is staged
+        check(lib.s2i_conv_forward_in(ctypes.byref(d), ptr(x), ptr(in_src.coef), wp, ptr(y), ptr(part), ptr(ws),
+                                      ws.numel() * 4, stream()), "s2i_conv_forward_in")
+        return y, part, nparts
     check(lib.s2i_conv_forward_cls(ctypes.byref(d), ptr(x), ptr(cvec), wp, ptr(bias), ptr(cls_bias), ptr(y), ptr(part),
                                    ptr(ws), ws.numel() * 4, stream()), "s2i_conv_forward")
     return y, part, nparts
 
 
-def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False, i_off=0, I_total=0):
+def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumulate=False, i_off=0, I_total=0, a_src=None):
     """Weight gradient into an OIHW tensor of shape grad_shape.  a: gathered NHWC, g: plain NHWC.
     With I_total > 0 only input channels [i_off, i_off + I) of a wider (O, I_total, KH, KW) tensor are written."""
     lib = _lib_ready()
@@ -477,7 +524,8 @@ def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumul
         O, I, KH, KW = grad_shape[0], grad_shape[1], 1, 1
     else:
         O, I, KH, KW = grad_shape
-    d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0, i_off, I_total)
+    d = WgradDesc(kind, B, H, W, Ca, Cc, N, N, swap, fold, O, I, KH, KW, 1 if accumulate else 0, i_off, I_total,
+                  a_src.act if a_src is not None else 0, a_src.groups if a_src is not None else 0)
     if EXEC_LOG is not None:
         Ho, Wo = _geom(kind, H, W)
         _log_exec("wgrad k%d a[%d,%d,%d,%d+%d] g%d" % (kind, B, H, W, Ca, Cc, N), B * Ho * Wo, N, _TAPS[kind] * (Ca + Cc),
@@ -485,6 +533,15 @@ def wgrad_raw(kind, a, cvec, g, grad_shape, *, swap=0, fold=0, out=None, accumul
     if out is None:
         full = grad_shape if not I_total else (O, I_total, KH, KW)
         out = torch.empty(full, dtype=torch.float32, device=a.device)
+    if a_src is not None:
+        # `a` is the producer's raw output; eligibility was checked by the caller (s2i_conv_wgrad_in_eligible)
+        wsb = lib.s2i_wgrad_workspace_bytes(ctypes.byref(d))
+        if wsb == 0:
+            check(1, "s2i_wgrad_workspace_bytes")
+        ws = _ws.get(wsb, a.device)
+        check(lib.s2i_conv_wgrad_in(ctypes.byref(d), ptr(a), ptr(a_src.coef), ptr(g), ptr(out), ptr(ws), ws.numel() * 4,
+                                    stream()), "s2i_conv_wgrad_in")
+        return out
     if MATH_PLANES:
         wsb = lib.s2i_wgrad_workspace_bytes_split(ctypes.byref(d), MATH_PLANES)
         if wsb == 0:
@@ -554,11 +611,14 @@ def _dgrad(kind_name, dy, w, packed, n_in, out_dtype=None):
     return y
 
 
-def _wgrad(kind_name, x, cvec, dy, weight):
-    """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode."""
+def _wgrad(kind_name, x, cvec, dy, weight, a_src=None):
+    """Weight gradient; accumulated into weight.grad in place (returns None) in direct mode.  a_src: x is the RAW output of
+    the producing block (deferred BatchNorm + LeakyReLU, applied by the gather)."""
     out, acc = (weight.grad, True) if _direct(weight) else (None, False)
 
     def run():
+        if a_src is not None:
+            return wgrad_raw(_KIND[kind_name], x, None, dy, tuple(weight.shape), out=out, accumulate=acc, a_src=a_src)
         if x.dtype == torch.bfloat16 or dy.dtype == torch.bfloat16:
             if cvec is not None:
                 raise _lib.S2IError("wgrad: bf16 operands carry their broadcast vector materialised")
@@ -617,8 +677,18 @@ def _tap_sums(dy):
 
 class ConvBnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training, groups=1):
+    def forward(ctx, x, cvec, weight, gamma, beta, residual, kind_name, act, bn_buffers, training, groups=1, defer=False):
         lib = _lib_ready()
+        # input produced by a block that deferred its BatchNorm + LeakyReLU: gather its raw output instead (apply-on-load)
+        in_src = _pending(x)
+        if in_src is not None:
+            if (cvec is None and residual is None and kind_name in ("k3s1", "k4s2") and not MATH_PLANES and training
+                    and in_src.y.dtype == torch.float32 and x.shape[-1] % 32 == 0 and weight.shape[0] > 4
+                    and in_src.groups == (groups if groups else 1)):
+                x = in_src.y
+            else:
+                real(x)
+                in_src = None
         x = x.contiguous()
         if cvec is not None:
             cvec = cvec.contiguous()
@@ -629,6 +699,8 @@ class ConvBnAct(torch.autograd.Function):
         # bf16 activation mode: every spatial block stores its raw conv output and its result as bf16 (the fc of
         # INIT_STAGE_G, kind k1, stays an fp32 island)
         bf = (ACT_BF16 and kind_name != "k1") or x.dtype == torch.bfloat16
+        if bf and in_src is not None:
+            raise _lib.S2IError("ConvBnAct: apply-on-load input in the bf16 activation mode")
         adt = torch.bfloat16 if bf else torch.float32
         cat_cc = 0
         if bf and cvec is not None and not factored:
@@ -656,7 +728,7 @@ class ConvBnAct(torch.autograd.Function):
             y, part, nparts = conv_any(kind, x, packed, Cout, stats=training, groups=groups, out_dtype=adt)
         else:
             y, part, nparts = conv_raw(kind, x, cvec, packed, Cout, wR=packed.shape[1], ldw=packed.shape[2],
-                                       stats=training, groups=groups)
+                                       stats=training, groups=groups, in_src=in_src)
         M = y.numel() // Cout
         if not training:
             groups = 1
@@ -671,10 +743,15 @@ class ConvBnAct(torch.autograd.Function):
         Cact = Cout // 2 if act == ACT_GLU else Cout
         out = torch.empty(y.shape[:-1] + (Cact,), dtype=adt, device=x.device)
         if residual is not None:
-            residual = cast(residual, adt).contiguous()
-        check(lib.s2i_bn_act_forward_dt(_dt(y), ptr(y), M, groups, Cout, ptr(coef), act, ptr(residual), ptr(out),
-                                        stream()), "s2i_bn_act_forward")
-        ctx.save_for_backward(x, cvec_used, weight, gamma, y, coef)
+            residual = cast(real(residual), adt).contiguous()
+        if defer and DEFER_ACT and training and act == ACT_LRELU and residual is None and not bf and not MATH_PLANES:
+            # the caller guarantees a single convolution consumer: `out` stays unwritten until real() or never
+            out._s2i_lazy = _Lazy(y, coef, act, groups)
+        else:
+            check(lib.s2i_bn_act_forward_dt(_dt(y), ptr(y), M, groups, Cout, ptr(coef), act, ptr(residual), ptr(out),
+                                            stream()), "s2i_bn_act_forward")
+        ctx.save_for_backward(x, cvec_used, weight, gamma, y, coef, None if in_src is None else in_src.coef)
+        ctx.in_src = None if in_src is None else (in_src.act, in_src.groups)
         ctx.beta_ref = beta
         ctx.kind_name, ctx.act, ctx.training, ctx.has_res = kind_name, act, training, residual is not None
         ctx.groups = groups
@@ -685,9 +762,14 @@ class ConvBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         lib = _lib_ready()
-        x, cvec, weight, gamma, y, coef = ctx.saved_tensors
+        x, cvec, weight, gamma, y, coef, in_coef = ctx.saved_tensors
         if not ctx.training:
             raise _lib.S2IError("ConvBnAct.backward: eval-mode BatchNorm has no backward on this path")
+        a_src = None
+        if ctx.in_src is not None:
+            # x is the producer's RAW output (apply-on-load forward): the weight gradient gathers it the same way where its
+            # plan allows, otherwise the activated operand is computed now
+            a_src = _Lazy(x, in_coef, ctx.in_src[0], ctx.in_src[1])
         Cout = weight.shape[0]
         M = y.numel() // Cout
         if dout.dtype != y.dtype:
@@ -732,7 +814,7 @@ class ConvBnAct(torch.autograd.Function):
             if need_w:
                 dw = _wgrad(ctx.kind_name, x, None, dy, weight)
             dres = dout if ctx.has_res else None
-            return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None
+            return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None, None
         if ctx.factored:
             packed = packed_weight(weight, PACK_PLAIN)
             Ip, Op = packed.shape[1], packed.shape[2]
@@ -765,9 +847,22 @@ class ConvBnAct(torch.autograd.Function):
             if not need_x:
                 dx = None
         if need_w and not ctx.factored:
-            dw = _wgrad(ctx.kind_name, x, cvec, dy, weight)
+            if a_src is not None:
+                B_, H_, W_, Ca_ = x.shape
+                O_, I_, KH_, KW_ = weight.shape
+                dd = WgradDesc(_KIND[ctx.kind_name], B_, H_, W_, Ca_, 0, dy.shape[-1], dy.shape[-1], 0, 0, O_, I_, KH_, KW_, 0,
+                               0, 0, a_src.act, a_src.groups)
+                if lib.s2i_conv_wgrad_in_eligible(ctypes.byref(dd)):
+                    dw = _wgrad(ctx.kind_name, x, None, dy, weight, a_src=a_src)
+                else:
+                    xa = torch.empty_like(x)
+                    check(lib.s2i_bn_act_forward_dt(_dt(x), ptr(x), x.numel() // Ca_, a_src.groups, Ca_, ptr(in_coef),
+                                                    a_src.act, None, ptr(xa), stream()), "s2i_bn_act_forward")
+                    dw = _wgrad(ctx.kind_name, xa, None, dy, weight)
+            else:
+                dw = _wgrad(ctx.kind_name, x, cvec, dy, weight)
         dres = dout if ctx.has_res else None
-        return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None
+        return dx, dc, dw, dgamma, dbeta, dres, None, None, None, None, None, None
 
 
 class ConvAct(torch.autograd.Function):
@@ -775,7 +870,7 @@ class ConvAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, kind_name, act, n_out):
-        x = x.contiguous()
+        x = real(x).contiguous()
         kind = _KIND[kind_name]
         packed = packed_weight(weight, PACK_PLAIN)
         if (ACT_BF16 and kind_name != "k1") or x.dtype == torch.bfloat16:
@@ -908,7 +1003,7 @@ class LogitHead(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         lib = _lib_ready()
         ctx.x_dtype = x.dtype
-        x = cast(x.contiguous(), torch.float32)   # a (B,4,4,C) map: the heads and the losses are an fp32 island
+        x = cast(real(x).contiguous(), torch.float32)   # a (B,4,4,C) map: the heads and the losses are an fp32 island
         B, H, W, C = x.shape
         if H != 4 or W != 4 or tuple(weight.shape) != (1, C, 4, 4):
             raise _lib.S2IError("LogitHead: expects a 4x4 map and a (1,C,4,4) weight")
@@ -1073,7 +1168,7 @@ class ToNCHW(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, C):
         lib = _lib_ready()
-        xk, ld = _rows_view(x)
+        xk, ld = _rows_view(real(x))
         B, H, W, Cp = x.shape
         out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
         check(lib.s2i_nhwc_to_nchw_dt(_dt(xk), ptr(xk), ld, ptr(out), B, C, H, W, stream()), "s2i_nhwc_to_nchw")

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, "declared in s2i_hip.h but not exported: %s" % missing
     unbound = sorted(declared - set(_lib.EXPORTED_SYMBOLS))
     assert not unbound, "declared in s2i_hip.h but not bound in _lib.py: %s" % unbound
-    assert lib.s2i_version() == _lib.ABI_VERSION == 3
+    assert lib.s2i_version() == _lib.ABI_VERSION == 4
 
 
 def test_descriptor_validation_reports_errors_without_a_gpu():

@@ -23,7 +23,6 @@ def make(graph):
     [d.apply(T.weights_init) for d in netsD]
     netG.to(dev); [d.to(dev) for d in netsD]
     tr = T.condGANTrainer(None, None, 256, False); tr.build(netG, netsD)
-    tr.d_priority = os.environ.get("PRIO", "1") == "1"
     if graph:
         tr.enable_graph(warmup=2, executor=graph)
     return tr
