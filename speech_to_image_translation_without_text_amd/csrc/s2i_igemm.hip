@@ -960,6 +960,85 @@ __global__ __launch_bounds__(256) void thin_out_kernel(IgemmP p, const float* __
   }
 }
 
+// ---- transposed conv to <= 4 channels from 64 (the image gradient of the discriminators' first conv, model.py:383) ------
+// The lanes-per-pixel kernel above ran this layer at 12 TFLOP/s-equivalent (0.27 ms for a 125 MB stream: every input pixel is
+// 256 bytes and four lanes-per-pixel groups re-read it per output phase).  Here a block owns 8 x 8 INPUT pixels (+ 1 halo):
+// the 10 x 10 x C patch is staged in LDS once with coalesced 16-byte loads, each of the four waves computes the 8 x 8 outputs
+// of ONE output phase (py, px), so its 2 x 2 taps' weights are wave-uniform and arrive as scalar loads from the
+// [phase][tap][c][4] table of thin_table_kernel; a lane reads its pixel's channels from LDS as 16-byte pieces (rows padded
+// to C + 4 floats: the 16 lanes of a read group hit distinct bank groups).  HBM-bound by construction: x read once, y written
+// once.
+template <int C>
+__global__ __launch_bounds__(256) void tconv_n4_tile_kernel(IgemmP p, const float* __restrict__ table) {
+  constexpr int LDP = C + 4;                       // floats per patch pixel in LDS
+  __shared__ __attribute__((aligned(16))) float patch[100 * LDP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int phase = __builtin_amdgcn_readfirstlane(tid >> 6), py = phase >> 1, px = phase & 1;
+  const int tilesX = p.W >> 3, tilesY = p.H >> 3;
+  const int tix = blockIdx.x % tilesX, tiy = (blockIdx.x / tilesX) % tilesY, b = blockIdx.x / (tilesX * tilesY);
+  const int iy0 = tiy * 8 - 1, ix0 = tix * 8 - 1;
+  // stage the patch: 100 pixels x C/4 float4 pieces
+  for (int e = tid; e < 100 * (C / 4); e += 256) {
+    const int pix = e / (C / 4), q = e - pix * (C / 4);
+    const int yl = pix / 10, xl = pix - yl * 10;
+    const int iy = iy0 + yl, ix = ix0 + xl;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+      const long long xe = (((long long)b * p.H + iy) * p.W + ix) * p.Cx + q * 4;
+      if (p.x16) {
+        const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+        v = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                  __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+      } else {
+        v = *reinterpret_cast<const f32x4*>(p.x + xe);
+      }
+    }
+    *reinterpret_cast<f32x4*>(patch + pix * LDP + q * 4) = v;
+  }
+  __syncthreads();
+  const int ly = lane >> 3, lx = lane & 7;                        // this lane's input pixel inside the tile
+  const float* __restrict__ wph = table + (size_t)phase * 4 * C * 4;   // [tap][c][4], wave-uniform
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int dy, dx;
+    tap_delta(S2I_TCONV_K4S2, 1, t, py, px, dy, dx);
+    const float* xp = patch + ((ly + 1 + dy) * 10 + (lx + 1 + dx)) * LDP;
+    const float* __restrict__ w = wph + (size_t)t * C * 4;
+#pragma unroll 4
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a0 = fmaf(v[j], w[(c0 + j) * 4 + 0], a0);
+        a1 = fmaf(v[j], w[(c0 + j) * 4 + 1], a1);
+        a2 = fmaf(v[j], w[(c0 + j) * 4 + 2], a2);
+        a3 = fmaf(v[j], w[(c0 + j) * 4 + 3], a3);
+      }
+    }
+  }
+  const int oy = 2 * (tiy * 8 + ly) + py, ox = 2 * (tix * 8 + lx) + px;
+  const long long row = ((long long)b * (2 * p.H) + oy) * (2 * p.W) + ox;
+  f32x4 o = {a0, a1, a2, a3};
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float v = o[n];
+    if (p.bias && n < p.N) v += p.bias[n];
+    if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+    else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+    else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+    o[n] = v;
+  }
+  if (p.N == 4 && !p.y16 && (p.ldy & 3) == 0) {
+    *reinterpret_cast<f32x4*>(p.y + row * p.ldy) = o;
+  } else {
+    for (int n = 0; n < p.N && n < 4; ++n) {
+      if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(o[n]);
+      else p.y[row * p.ldy + n] = o[n];
+    }
+  }
+}
+
 // 4 input channels, NOUT outputs: y[pix][n] = act(sum_{t,ci} x[pix + t][ci] * table[t][ci][n])
 template <int NOUT>
 __global__ __launch_bounds__(256) void thin_in_kernel(IgemmP p, const float* __restrict__ table) {
@@ -2276,6 +2355,11 @@ static int thin_kind(const s2i_conv_desc* d, const FwdPlan& pl) {
   if (pl.Ca == 4 && d->kind == S2I_CONV_K3S1 && (d->N == 16 || d->N == 32) && (d->ldy % 8) == 0) return 2;
   return 0;
 }
+// transposed conv to <= 4 channels from 64 stored channels on maps of whole 8 x 8 tiles: tconv_n4_tile_kernel
+static bool tile_n4_ok(const s2i_conv_desc* d, const FwdPlan& pl) {
+  return d->kind == S2I_TCONV_K4S2 && d->N <= 4 && d->Cc == 0 && !d->stats && pl.Ca == 64 && (d->H % 8) == 0 && (d->W % 8) == 0 &&
+         pl.M >= 4096 && pl.splitk == 1;
+}
 static size_t thin_table_floats(const s2i_conv_desc* d, const FwdPlan& pl, int tk) {
   return tk == 1 ? (size_t)pl.nphases * pl.T * pl.Ca * 4 : (size_t)pl.T * 4 * d->N;
 }
@@ -2308,7 +2392,8 @@ extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
   // the caller does not know which kernel the dtypes will select: the largest requirement of the candidates
   size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
   if (tk) { const size_t tb = thin_table_floats(d, pl, tk) * sizeof(float); need = tb > need ? tb : need; }
-  if (rgb || tk) return rgb > need ? rgb : need;
+  if (tile_n4_ok(d, pl)) { const size_t tb = (size_t)4 * 4 * 64 * 4 * sizeof(float); need = tb > need ? tb : need; }
+  if (rgb || tk || tile_n4_ok(d, pl)) return rgb > need ? rgb : need;
   return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
 }
 
@@ -2438,6 +2523,16 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     S2I_REQUIRE((pl.M % g) == 0 && (g == 1 || ((pl.M / g) % pl.bm) == 0),
                 "conv(apply-on-load): %d rows do not split into %d producer groups of whole %d-row tiles", pl.M, g, pl.bm);
     p.in_rows_per_group = pl.M / g;
+  }
+  if (!wsp && !cls_bias && !in_coef && tile_n4_ok(d, pl) && !y16 && ws && ws_bytes >= (size_t)4 * 4 * 64 * 4 * sizeof(float)) {
+    float* table = (float*)ws;
+    const int total = 4 * 4 * 64 * 4;
+    hipLaunchKernelGGL(thin_table_kernel, dim3(s2i_cdiv(total, 256)), dim3(256), 0, st, w, table, d->kind, d->flip, pl.T,
+                       d->wmode != 0 ? 1 : 0, d->wR, d->ldw, 64, 4, 4);
+    S2I_LAUNCH_CHECK("thin_table");
+    hipLaunchKernelGGL((tconv_n4_tile_kernel<64>), dim3((d->H / 8) * (d->W / 8) * d->B), dim3(256), 0, st, p, (const float*)table);
+    S2I_LAUNCH_CHECK("tconv_n4_tile");
+    return 0;
   }
   const int rk = (!wsp && !cls_bias && !in_coef) ? rgb_kind(d, pl, x16, y16) : 0;
   if (rk && ws && ws_bytes >= rgb_afrag_elems(d, pl, rk) * 2 && !(rk == 2 && bias)) {
