@@ -1039,6 +1039,77 @@ __global__ __launch_bounds__(256) void tconv_n4_tile_kernel(IgemmP p, const floa
   }
 }
 
+// conv3x3 to <= 4 channels (GET_IMAGE_G, model.py:287-298) from 16 / 32 / 64 channels, the same construction: a block owns
+// 16 x 16 output pixels, stages the 18 x 18 patch of (up to) 32 channels in LDS with coalesced 16-byte loads, one lane per
+// output pixel, all nine taps' weights wave-uniform from the [tap][c][4] table.  x read once (+ 27 % halo), y written once.
+template <int CCH>
+__global__ __launch_bounds__(256) void conv3_n4_tile_kernel(IgemmP p, const float* __restrict__ table) {
+  constexpr int LDP = CCH + 4;
+  __shared__ __attribute__((aligned(16))) float patch[324 * LDP];
+  const int tid = threadIdx.x;
+  const int tilesX = p.W >> 4, tilesY = p.H >> 4;
+  const int tix = blockIdx.x % tilesX, tiy = (blockIdx.x / tilesX) % tilesY, b = blockIdx.x / (tilesX * tilesY);
+  const int iy0 = tiy * 16 - 1, ix0 = tix * 16 - 1;
+  const int ly = tid >> 4, lx = tid & 15;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int cb = 0; cb < p.Ca; cb += CCH) {
+    if (cb) __syncthreads();
+    for (int e = tid; e < 324 * (CCH / 4); e += 256) {
+      const int pix = e / (CCH / 4), q = e - pix * (CCH / 4);
+      const int yl = pix / 18, xl = pix - yl * 18;
+      const int iy = iy0 + yl, ix = ix0 + xl;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+        const long long xe = (((long long)b * p.H + iy) * p.W + ix) * p.Cx + cb + q * 4;
+        if (p.x16) {
+          const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.x) + xe);
+          v = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                    __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+        } else {
+          v = *reinterpret_cast<const f32x4*>(p.x + xe);
+        }
+      }
+      *reinterpret_cast<f32x4*>(patch + pix * LDP + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float* xp = patch + ((ly + t / 3) * 18 + lx + t % 3) * LDP;
+      const float* __restrict__ w = table + ((size_t)t * p.Ca + cb) * 4;     // wave-uniform
+#pragma unroll 4
+      for (int c0 = 0; c0 < CCH; c0 += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + c0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a0 = fmaf(v[j], w[(c0 + j) * 4 + 0], a0);
+          a1 = fmaf(v[j], w[(c0 + j) * 4 + 1], a1);
+          a2 = fmaf(v[j], w[(c0 + j) * 4 + 2], a2);
+          a3 = fmaf(v[j], w[(c0 + j) * 4 + 3], a3);
+        }
+      }
+    }
+  }
+  const long long row = ((long long)b * p.H + tiy * 16 + ly) * p.W + tix * 16 + lx;
+  f32x4 o = {a0, a1, a2, a3};
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float v = o[n];
+    if (p.bias && n < p.N) v += p.bias[n];
+    if (p.act == S2I_ACT_LRELU) v = v > 0.f ? v : 0.2f * v;
+    else if (p.act == S2I_ACT_TANH) v = tanhf(v);
+    else if (p.act == S2I_ACT_RELU) v = fmaxf(v, 0.f);
+    o[n] = v;
+  }
+  if (p.N == 4 && !p.y16 && (p.ldy & 3) == 0) {
+    *reinterpret_cast<f32x4*>(p.y + row * p.ldy) = o;
+  } else {
+    for (int n = 0; n < p.N && n < 4; ++n) {
+      if (p.y16) reinterpret_cast<unsigned short*>(p.y)[row * p.ldy + n] = f2bf(o[n]);
+      else p.y[row * p.ldy + n] = o[n];
+    }
+  }
+}
+
 // 4 input channels, NOUT outputs: y[pix][n] = act(sum_{t,ci} x[pix + t][ci] * table[t][ci][n])
 template <int NOUT>
 __global__ __launch_bounds__(256) void thin_in_kernel(IgemmP p, const float* __restrict__ table) {
@@ -1953,32 +2024,53 @@ __global__ __launch_bounds__(256) void small_n_wgrad_kernel(WgradP p) {
     for (int j = 0; j < 4; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int ngroups = p.M / PPW;  // W is a power of two >= PPW, so a group never straddles an image row
   const int wmask = p.W - 1;
-  for (int grp = blockIdx.x * 4 + wave; grp < ngroups; grp += gridDim.x * 4) {
-    const int m = grp * PPW + pl;
-    const int ix = m & wmask;
-    const int iy = (m >> p.lgWo) & (p.H - 1);
-    f32x4 av;
+  // two pixel groups per trip: both groups' loads (their input quads and the 2 x 9 output-gradient pixels) are issued before
+  // the first product, which doubles the bytes each wave keeps in flight -- the kernel is a latency-bound stream at two waves
+  // per SIMD (144 accumulators), 147 us for 125 MB with one group per trip
+  auto load_a = [&](int m) -> f32x4 {
     if (p.a16) {
       const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(p.a) + (size_t)m * p.Ca + q * 4);
-      av = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
-                 __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
-    } else {
-      av = *reinterpret_cast<const f32x4*>(p.a + (size_t)m * p.Ca + q * 4);
+      return f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
     }
+    return *reinterpret_cast<const f32x4*>(p.a + (size_t)m * p.Ca + q * 4);
+  };
+  auto load_g = [&](int m, f32x4 (&gv)[9]) {
+    const int ix = m & wmask;
+    const int iy = (m >> p.lgWo) & (p.H - 1);
     const float* gp = p.g + (size_t)m * 4;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      const int oy = iy + 1 - dy;
-      if (oy < 0 || oy >= p.H) continue;
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
-        const int ox = ix + 1 - dx;
-        if (ox < 0 || ox >= p.W) continue;
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + ((1 - dy) * p.W + (1 - dx)) * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[dy * 3 + dx][j] += av[j] * gv;
+        const int oy = iy + 1 - dy, ox = ix + 1 - dx;
+        const bool ok = oy >= 0 && oy < p.H && ox >= 0 && ox < p.W;
+        gv[dy * 3 + dx] = ok ? *reinterpret_cast<const f32x4*>(gp + ((1 - dy) * p.W + (1 - dx)) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    }
+  };
+  auto fma9 = [&](const f32x4& av, const f32x4 (&gv)[9]) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][j] += av[j] * gv[t];
+  };
+  const int stride = gridDim.x * 4;
+  int grp = blockIdx.x * 4 + wave;
+  for (; grp + stride < ngroups; grp += 2 * stride) {
+    const int m0 = grp * PPW + pl, m1 = (grp + stride) * PPW + pl;
+    f32x4 g0[9], g1[9];
+    const f32x4 av0 = load_a(m0), av1 = load_a(m1);
+    load_g(m0, g0);
+    load_g(m1, g1);
+    fma9(av0, g0);
+    fma9(av1, g1);
+  }
+  if (grp < ngroups) {
+    const int m0 = grp * PPW + pl;
+    f32x4 g0[9];
+    const f32x4 av0 = load_a(m0);
+    load_g(m0, g0);
+    fma9(av0, g0);
   }
   // lanes with equal q (different pixels) -> lane q
 #pragma unroll
@@ -2360,6 +2452,11 @@ static bool tile_n4_ok(const s2i_conv_desc* d, const FwdPlan& pl) {
   return d->kind == S2I_TCONV_K4S2 && d->N <= 4 && d->Cc == 0 && !d->stats && pl.Ca == 64 && (d->H % 8) == 0 && (d->W % 8) == 0 &&
          pl.M >= 4096 && pl.splitk == 1;
 }
+// conv3x3 to <= 4 channels from 16 / 32 / 64 stored channels on maps of whole 16 x 16 tiles: conv3_n4_tile_kernel
+static bool tile3_n4_ok(const s2i_conv_desc* d, const FwdPlan& pl) {
+  return d->kind == S2I_CONV_K3S1 && d->N <= 4 && d->Cc == 0 && !d->stats && (pl.Ca == 16 || pl.Ca == 32 || pl.Ca == 64) &&
+         (d->H % 16) == 0 && (d->W % 16) == 0 && pl.M >= 4096 && pl.splitk == 1;
+}
 static size_t thin_table_floats(const s2i_conv_desc* d, const FwdPlan& pl, int tk) {
   return tk == 1 ? (size_t)pl.nphases * pl.T * pl.Ca * 4 : (size_t)pl.T * 4 * d->N;
 }
@@ -2393,7 +2490,8 @@ extern "C" size_t s2i_conv_workspace_bytes(const s2i_conv_desc* d) {
   size_t need = pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
   if (tk) { const size_t tb = thin_table_floats(d, pl, tk) * sizeof(float); need = tb > need ? tb : need; }
   if (tile_n4_ok(d, pl)) { const size_t tb = (size_t)4 * 4 * 64 * 4 * sizeof(float); need = tb > need ? tb : need; }
-  if (rgb || tk || tile_n4_ok(d, pl)) return rgb > need ? rgb : need;
+  if (tile3_n4_ok(d, pl)) { const size_t tb = (size_t)9 * pl.Ca * 4 * sizeof(float); need = tb > need ? tb : need; }
+  if (rgb || tk || tile_n4_ok(d, pl) || tile3_n4_ok(d, pl)) return rgb > need ? rgb : need;
   return pl.splitk > 1 ? (size_t)pl.splitk * pl.Mrows * d->N * sizeof(float) : 0;
 }
 
@@ -2532,6 +2630,18 @@ static int conv_forward_impl(const s2i_conv_desc* d, const float* x, const float
     S2I_LAUNCH_CHECK("thin_table");
     hipLaunchKernelGGL((tconv_n4_tile_kernel<64>), dim3((d->H / 8) * (d->W / 8) * d->B), dim3(256), 0, st, p, (const float*)table);
     S2I_LAUNCH_CHECK("tconv_n4_tile");
+    return 0;
+  }
+  if (!wsp && !cls_bias && !in_coef && tile3_n4_ok(d, pl) && !y16 && ws && ws_bytes >= (size_t)9 * pl.Ca * 4 * sizeof(float)) {
+    float* table = (float*)ws;
+    const int total = 9 * pl.Ca * 4;
+    hipLaunchKernelGGL(thin_table_kernel, dim3(s2i_cdiv(total, 256)), dim3(256), 0, st, w, table, d->kind, d->flip, pl.T,
+                       d->wmode != 0 ? 1 : 0, d->wR, d->ldw, pl.Ca, 4, 1);
+    S2I_LAUNCH_CHECK("thin_table");
+    const dim3 g3((d->H / 16) * (d->W / 16) * d->B);
+    if (pl.Ca == 16) hipLaunchKernelGGL((conv3_n4_tile_kernel<16>), g3, dim3(256), 0, st, p, (const float*)table);
+    else hipLaunchKernelGGL((conv3_n4_tile_kernel<32>), g3, dim3(256), 0, st, p, (const float*)table);
+    S2I_LAUNCH_CHECK("conv3_n4_tile");
     return 0;
   }
   const int rk = (!wsp && !cls_bias && !in_coef) ? rgb_kind(d, pl, x16, y16) : 0;
