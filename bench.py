@@ -37,6 +37,8 @@ def parse():
                          "log-mel input inside every step and feed its output as the embedding")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel launches (the command profiled for profiles/*roofline*)")
+    ap.add_argument("--roofline-kernel", default=None, choices=[None, "conv", "wgrad"],
+                    help="with --roofline-only --math bf16: the convolution kernel (default) or the weight-gradient kernel")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL over xGMI); gloo only to rehearse the rank logic")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank on cuda:0 (gloo only)")
     ap.add_argument("--cpu-baseline-batch", type=int, default=24)
@@ -65,6 +67,19 @@ def synthetic_batch(B, dev, seed):
 PROFILED_JSON = os.path.join(ROOT, "profiles", "roofline_profiled.json")
 
 
+def sources_sha16():
+    """Hash of the kernel sources: the committed profile numbers name the sources they were collected with, and the line says
+    whether they still describe the code that ran."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def profiled_numbers(key):
     """Numbers of the dominant kernel that cannot be measured live inside this process: the rocprofv3 kernel-trace
     average duration and the PMC HBM traffic of the SAME launch (`bench.py --roofline-only [--math ...]` under
@@ -72,9 +87,13 @@ def profiled_numbers(key):
     read from; None when no committed profile covers this configuration."""
     try:
         with open(PROFILED_JSON) as fh:
-            return json.load(fh).get(key)
+            ent = json.load(fh).get(key)
     except (OSError, ValueError):
         return None
+    if ent is not None:
+        ent = dict(ent)
+        ent["matches_sources"] = ent.get("sources_sha16") == sources_sha16()   # False: collected with other kernel sources
+    return ent
 
 
 def _time_launch(fn, reps=20):
@@ -110,7 +129,7 @@ def bf16_kernel_roofline(dev, B):
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
             "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
             "frac_profiled": round(abytes / (prof["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4) if prof.get("avg_ns") else None,
-            "profiled_source": prof.get("avg_source"),
+            "profiled_source": prof.get("avg_source"), "profile_matches_sources": prof.get("matches_sources"),
             "kernel": "conv_bf16_v2_kernel<K4S2, CK 32, 4 taps per stage, 66-pixel padded patch rows> (v_mfma_f32_32x32x16_bf16; "
                       "256-pixel x 128-channel tiles, LDS-staged 18x66-pixel input patch, one persistent block per CU "
                       "prefetching its next tile)",
@@ -121,13 +140,44 @@ def bf16_kernel_roofline(dev, B):
             "note": "this layer sits at the bf16 ridge (341 FLOP/B against 312): both fractions are reported"}
 
 
-def dominant_kernel_roofline(dev, B, math="f32"):
+def bf16_wgrad_roofline(dev, B):
+    """bf16 mode: the kernel family with the largest per-step time (profiles/r03_bf16_b48_step_kernel_stats.md):
+    igemm_wgrad_b16_kernel<128,128>, on its heaviest launch -- the weight gradient of D_NET256's Conv2d(64,128,k4,s2,p1) over
+    the stacked batch: a = (3B,128,128,64) bf16 gathered per tap, g = (3B,64,64,128) bf16.  Algorithmic bytes: both operands
+    read once (the fp32 slabs and the OIHW result are < 1 % of that)."""
+    from speech_to_image_translation_without_text_amd import ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K4S2
+    n = 3 * B
+    a = torch.randn(n, 128, 128, 64, device=dev).to(torch.bfloat16)
+    g = torch.randn(n, 64, 64, 128, device=dev).to(torch.bfloat16)
+    out = torch.zeros(128, 64, 4, 4, device=dev)
+    fn = lambda: ops.wgrad_any(CONV_K4S2, a, g, (128, 64, 4, 4), out=out)
+    ms = _time_launch(fn)
+    flops = 2.0 * (n * 64 * 64) * 128 * (16 * 64)
+    abytes = a.numel() * 2 + g.numel() * 2
+    gbs = abytes / (ms * 1e-3) / 1e9
+    prof = profiled_numbers("bf16_wgrad_b%d" % B) or {}
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
+            "frac_profiled": round(abytes / (prof["avg_ns"] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4) if prof.get("avg_ns") else None,
+            "profiled_source": prof.get("avg_source"), "profile_matches_sources": prof.get("matches_sources"),
+            "kernel": "igemm_wgrad_b16_kernel<128,128,2,2> + slab sum + OIHW finish (v_mfma_f32_32x32x16_bf16; 64-pixel stages, "
+                      "pixel-major LDS images read with ds_read_b64_tr_b16, fp32 slabs per pixel range)",
+            "algorithmic_bytes": abytes,
+            "mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1), "mfma_frac_of_2500": round(flops / (ms * 1e-3) / 2.5e15, 4),
+            "launch": "weight gradient of Conv2d(64,128,k4,s2,p1): a (%d,128,128,64) x g (%d,64,64,128) bf16, %.1f MB algorithmic, "
+                      "%.2f GFLOP, %.3f ms (incl. the slab reduction and finish launches)" % (n, n, abytes / 1e6, flops / 1e9, ms),
+            "note": "largest kernel family of the config-4 step by time (2.1 of 22 ms of kernel time); the convolution kernel's "
+                    "roofline is reported beside it as roofline_conv"}
+
+
+def dominant_kernel_roofline(dev, B, math="f32", which=None):
     """Live HIP-event timing of the dominant kernel: the fp32-MFMA implicit-GEMM convolution, on the
     heaviest single layer of the step (D_NET256 img_code_s16[2]: Conv2d(64,128,k4,s2,p1) on 128x128)."""
     from speech_to_image_translation_without_text_amd import ops
     from speech_to_image_translation_without_text_amd._lib import CONV_K4S2, PACK_PLAIN
     if math == "bf16":
-        return bf16_kernel_roofline(dev, B)
+        return bf16_wgrad_roofline(dev, B) if which == "wgrad" else bf16_kernel_roofline(dev, B)
     if math == "bf16p":
         math = "bf16"
     x = torch.randn(B, 128, 128, 64, device=dev)
@@ -158,7 +208,7 @@ def dominant_kernel_roofline(dev, B, math="f32"):
            "traffic": prof.get("traffic_bytes"), "traffic_source": prof.get("traffic_source"),
            "frac_profiled": (round(flops / (prof["avg_ns"] * 1e-9) / 1e12 / PEAK_F32_TFLOPS, 4)
                              if prof.get("avg_ns") else None),
-           "profiled_source": prof.get("avg_source"),
+           "profiled_source": prof.get("avg_source"), "profile_matches_sources": prof.get("matches_sources"),
            "kernel": kernel,
            "launch": "Conv2d(64,128,k4,s2,p1) on (%d,128,128,64) NHWC, %.2f GFLOP/launch, %.3f ms" % (B, flops / 1e9, ms)}
     if math != "f32":
@@ -252,7 +302,8 @@ def bf16_side_leg(dev, args, model, ops, T, cfg, B=48):
            "dtype": "bf16", "note": MATH_NOTE["bf16"],
            "step_hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
            "losses": {"errD_total": losses[0], "errG_total": losses[1], "kl": losses[2]},
-           "roofline": bf16_kernel_roofline(dev, B)}
+           # the family with the largest per-step time first (weight gradient), the convolution kernel beside it
+           "roofline": bf16_wgrad_roofline(dev, B), "roofline_conv": bf16_kernel_roofline(dev, B)}
     del tr, netG, netsD
     torch.cuda.empty_cache()
     return res
@@ -280,7 +331,7 @@ def main():
     ops.MATH_PLANES = {"f32": 0, "bf16x3": 3, "bf16x2": 2, "bf16": 0, "bf16p": 1}[args.math]
     ops.ACT_BF16 = args.math == "bf16"
     if args.roofline_only:
-        print(json.dumps({"roofline": dominant_kernel_roofline(dev, args.batch, args.math)}))
+        print(json.dumps({"roofline": dominant_kernel_roofline(dev, args.batch, args.math, args.roofline_kernel)}))
         return
     cfg_from_file(os.path.join(ROOT, "speech_to_image_translation_without_text_amd", "cfg", "birds_3stages.yml"))
     cfg.TRAIN.BATCH_SIZE = args.batch
@@ -416,7 +467,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 line["rccl_version"] = "unavailable: %s" % str(e)[:60]
         if world == 1:
-            line["roofline"] = dominant_kernel_roofline(dev, B, args.math)
+            if args.math == "bf16":
+                # config 4: the kernel family with the largest per-step time (weight gradient), the convolution beside it
+                line["roofline"] = dominant_kernel_roofline(dev, B, args.math, "wgrad")
+                line["roofline_conv"] = dominant_kernel_roofline(dev, B, args.math, "conv")
+            else:
+                line["roofline"] = dominant_kernel_roofline(dev, B, args.math)
             if args.math == "f32" and not args.no_side_leg:
                 # reported beside the value, never as the value: the same step with the split-bf16 matrix products
                 try:

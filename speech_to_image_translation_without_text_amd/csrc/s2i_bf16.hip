@@ -90,14 +90,31 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int l31 = lane & 31, lh = lane >> 5;
-  int phase = 0, split = blockIdx.z;
-  if (KIND == KB_TCONV) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  // XCD-aware block order (round 3).  The gridDim.y channel blocks and the gridDim.z phases / K splits of ONE pixel tile
+  // read the same input patch; blocks are dealt round-robin over the 8 XCDs (an L2 each), and in launch order the
+  // siblings of a tile are gridDim.x ids apart: another XCD, another time.  Linear id L -> (tile, sibling) such that all
+  // siblings of a tile have the same L % 8 and consecutive ids on that XCD (a bijection: the last group of tiles uses
+  // its own modulus).
+  int bx, by, bz;
+  {
+    const int sib = gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per_group = 8 * sib;
+    const int grp = L / per_group, Ll = L - grp * per_group;
+    const int in_group = min(8, (int)gridDim.x - grp * 8);
+    bx = grp * 8 + Ll % in_group;
+    const int u = Ll / in_group;
+    by = u % gridDim.y;
+    bz = u / gridDim.y;
+  }
+  int phase = 0, split = bz;
+  if (KIND == KB_TCONV) { phase = bz / p.splitk; split = bz - phase * p.splitk; }
   const int py = phase >> 1, px = phase & 1;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
   const int TW = 1 << p.lgTW, TH = 1 << p.lgTH;
-  const int tix = blockIdx.x & (p.tilesX - 1);
-  const int tiy = (blockIdx.x / p.tilesX) & (p.tilesY - 1);
-  const int tib = blockIdx.x / (p.tilesX * p.tilesY);
+  const int tix = bx & (p.tilesX - 1);
+  const int tiy = (bx / p.tilesX) & (p.tilesY - 1);
+  const int tib = bx / (p.tilesX * p.tilesY);
   const int b0 = tib << p.lgTB, oy0 = tiy << p.lgTH, ox0 = tix << p.lgTW;
   const int PW = p.PW, PH = p.PH;
   // input coordinate of patch pixel (0, 0)
@@ -398,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16_kernel(ConvBP p) {
           sv += red[(0 * WAVES_M + q) * BN + tid];
           sq += red[(1 * WAVES_M + q) * BN + tid];
         }
-        const int gm = phase * gridDim.x + blockIdx.x;
+        const int gm = phase * gridDim.x + bx;
         p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
         p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
       }

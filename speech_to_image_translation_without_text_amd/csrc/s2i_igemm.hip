@@ -193,10 +193,25 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  int phase = 0, split = blockIdx.z;
-  if (p.kind == S2I_TCONV_K4S2) { phase = blockIdx.z / p.splitk; split = blockIdx.z - phase * p.splitk; }
+  // XCD-aware block order (round 3): the column blocks, phases and K splits of ONE row tile gather the same input pixels;
+  // launch order puts them gridDim.x ids apart (another XCD's L2, another time).  Linear id -> (row tile, sibling) with all
+  // siblings of a row tile on one XCD (same id % 8) and adjacent there; a bijection for any grid.
+  int bx, by, bz;
+  {
+    const int sib = gridDim.y * gridDim.z;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int per_group = 8 * sib;
+    const int grp = L / per_group, Ll = L - grp * per_group;
+    const int in_group = min(8, (int)gridDim.x - grp * 8);
+    bx = grp * 8 + Ll % in_group;
+    const int u = Ll / in_group;
+    by = u % gridDim.y;
+    bz = u / gridDim.y;
+  }
+  int phase = 0, split = bz;
+  if (p.kind == S2I_TCONV_K4S2) { phase = bz / p.splitk; split = bz - phase * p.splitk; }
   const int py = phase >> 1, px = phase & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   const int kq = tid & 7, mrow = tid >> 3;
   int s, pad, kw;
   geom(p, p.kind, s, pad, kw);
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(256, 3) void igemm_fwd_kernel(IgemmP p) {
           sv += red[(0 * WAVES_M + q) * BN + tid];
           sq += red[(1 * WAVES_M + q) * BN + tid];
         }
-        const int gm = phase * gridDim.x + blockIdx.x;
+        const int gm = phase * gridDim.x + bx;
         p.part[((size_t)0 * p.nparts + gm) * p.N + n] = sv;
         p.part[((size_t)1 * p.nparts + gm) * p.N + n] = sq;
       }
@@ -1413,6 +1428,22 @@ struct WgradP {
   int a_groups, a_ipg;   // BatchNorm groups of the producer, images per group
 };
 
+// XCD-aware block order of the weight-gradient grids (tiles x pixel-range splits).  Every tile of ONE split reads the same
+// pixels of both operands, and blocks are dealt round-robin over the chip's 8 XCDs, each with an L2 of its own
+// (MI355X_MICROARCH.md): in launch order (tile fastest) the 8 k-tiles of a split land on 8 different XCDs and every one of
+// them pulls the split's `g` rows through the fabric (profiles/r03_roofline_bf16_wgrad_b48: 1.25 GB fetched for 453 MB of
+// operands).  Here linear block id L maps to (tile, split) such that all tiles of a split have the same L % 8 -- one XCD --
+// and consecutive ids on that XCD; a bijection for any split count (the last group of splits uses its own modulus).
+__device__ __forceinline__ void wgrad_block_map(int& tile, int& split) {
+  const int tiles = gridDim.x * gridDim.y, nsplit = gridDim.z;
+  const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const int per_group = 8 * tiles;
+  const int grp = L / per_group, Ll = L - grp * per_group;
+  const int in_group = min(8, nsplit - grp * 8);         // splits of this group (the last one may hold fewer)
+  split = grp * 8 + Ll % in_group;
+  tile = Ll / in_group;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AACT = false>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
@@ -1427,7 +1458,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(
   float* Bs = smem + 32 * LDA;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  int tile_, split;
+  wgrad_block_map(tile_, split);
+  const int k0 = (tile_ % gridDim.x) * BM, n0 = (tile_ / gridDim.x) * BN;
   int s, pad, kw;
   geom(p.kind, s, pad, kw);
 
@@ -1738,7 +1771,9 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_b16_kernel(WgradP p) {
   unsigned char* Bs = smem + PC * AROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int k0 = blockIdx.x * BM, n0 = blockIdx.y * BN, split = blockIdx.z;
+  int tile_, split;
+  wgrad_block_map(tile_, split);
+  const int k0 = (tile_ % gridDim.x) * BM, n0 = (tile_ / gridDim.x) * BN;
   int s, pad, kw;
   geom(p.kind, s, pad, kw);
   const int acol8 = tid % ATPR, arow = tid / ATPR;
