@@ -223,6 +223,8 @@ _D_STREAMS = {}   # (device, number of discriminators, priorities) -> per-discri
 
 
 class condGANTrainer(object):
+    d_overlap_min = 1 << 20     # smallest tail (elements) of a discriminator's flat gradient worth a second all-reduce
+
     def __init__(self, output_dir, data_loader, imsize, my_dataset_flag, local_rank=0, distributed=False):
         self.my_dataset_flag = my_dataset_flag
         if output_dir is not None:
@@ -358,7 +360,7 @@ class condGANTrainer(object):
             if k == 0 or k >= len(flat.params):
                 continue
             split = flat.offsets[k]
-            if flat.g.numel() - split < (1 << 20):
+            if flat.g.numel() - split < self.d_overlap_min:
                 continue                                   # a tail below 4 MB is not worth a second collective
             self._d_split[idx] = split
 

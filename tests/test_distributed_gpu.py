@@ -20,7 +20,6 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    os.environ["S2I_D_OVERLAP_MIN"] = "0"      # the reduced-width discriminators are small: split their all-reduce anyway
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import CASES, build_nets, make_batch
@@ -35,6 +34,7 @@ def _worker(rank, world, port, out_dir):
         for d in netsD:
             d.to(dev)
         tr = T.condGANTrainer(None, None, 256, False, local_rank=0, distributed=True)
+        tr.d_overlap_min = 0         # the reduced-width discriminators are small: split their all-reduce anyway
         tr.build(netG, netsD)
         # D_NET128 / D_NET256 reduce in two chunks (tower + heads from a backward hook, then img_code_s16); at this batch
         # (not a multiple of 8) the three passes are separate calls, so the hook must wait for its third firing
@@ -77,7 +77,6 @@ def _rccl_worker(rank, world, port, out_dir):
     bit-identical to the non-distributed step."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    os.environ["S2I_D_OVERLAP_MIN"] = "0"
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     dev = torch.device("cuda:0")
@@ -97,6 +96,7 @@ def _rccl_worker(rank, world, port, out_dir):
             for d in netsD:
                 d.to(dev)
             tr = T.condGANTrainer(None, None, 256, False, local_rank=0, distributed=distributed)
+            tr.d_overlap_min = 0     # the reduced-width discriminators are small: split their all-reduce anyway
             tr.build(netG, netsD)
             if distributed:
                 assert tr._g_split is not None and 0 < tr._g_split < tr.flatG.total
