@@ -70,7 +70,7 @@ def test_two_ranks_on_one_gpu_stay_identical(gpu, tmp_path):
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
 
 
-def _rccl_worker(rank, world, port, out_dir):
+def _rccl_worker(rank, world, port, out_dir, bf16=False):
     """World-size-1 `nccl` (= RCCL) process group, created before any other GPU call: the collectives of the data-parallel
     step (rank-0 broadcast of parameters and BatchNorm buffers, per-network flat all-reduce issued from the discriminator
     streams, the two-chunk G all-reduce started from a backward hook) run through RCCL itself, and must leave the result
@@ -83,7 +83,8 @@ def _rccl_worker(rank, world, port, out_dir):
     torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         from helpers import CASES, build_nets, make_batch
-        from speech_to_image_translation_without_text_amd import trainer as T
+        from speech_to_image_translation_without_text_amd import ops, trainer as T
+        ops.ACT_BF16 = bool(bf16)      # config 4 names an 8-GPU leg: the bf16 re-pack after Adam sits between the all-reduce wait and the next forward
         torch.cuda.set_device(0)
         case = dict(CASES["small3"], B=8)
         batch = make_batch(case)
@@ -117,7 +118,8 @@ def _rccl_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_world_size_one_rccl_group_matches_single_process(gpu, tmp_path):
-    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_world_size_one_rccl_group_matches_single_process(gpu, tmp_path, bf16):
+    mp.spawn(_rccl_worker, args=(1, _free_port(), str(tmp_path), bf16), nprocs=1, join=True)
     assert (tmp_path / "ok0").exists()
     print((tmp_path / "ok0").read_text())
