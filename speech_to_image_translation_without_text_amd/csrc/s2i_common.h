@@ -41,6 +41,7 @@ enum {
   S2I_TUNE_FWD_MIN_CPS,     // fwd_min_cps: fewest 32-deep K chunks a split-K block keeps
   S2I_TUNE_B16_V2,          // b16_v2: 0 never / 1 where eligible and >= 224 tiles / 2 wherever eligible
   S2I_TUNE_B16_PERSIST,     // b16_persist: 0 off / 1 one block per CU / n block slots (tests)
+  S2I_TUNE_FINALIZE_THREADS, // finalize_threads: thread cap of a BatchNorm finalize block (default 256)
   S2I_TUNE_B16_DBG,         // b16_dbg: diagnostic instantiation of the bf16 convolution kernels (libs2i_hip_diag.so only)
   S2I_TUNE_COUNT
 };

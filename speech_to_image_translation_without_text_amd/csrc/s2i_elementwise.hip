@@ -1364,9 +1364,13 @@ static int launch_finalize(int mode, const float* part, int nparts, int groups, 
   int qpb = 1;
   while (qpb < 32 && qpb * 32 < Q) qpb <<= 1;
   const int grid = (Q + qpb - 1) / qpb;
-  // row lanes per group: a power of two, no more than the list is long, groups side by side in at most 1024 threads
+  // row lanes per group: a power of two, no more than the list is long, groups side by side in at most 256 threads.  (1024
+  // threads and 64 KB of LDS until round 3: such a block cannot start on a CU that runs three matrix blocks of another stream
+  // -- 123 KB of LDS, 12 of 16 wave slots -- and waited for the tail of that kernel: 44 us per finalize inside the step against
+  // 10 us alone.  A 256-thread block with 16 KB fits beside them.)
+  const int cap = s2i_tune(S2I_TUNE_FINALIZE_THREADS, 256);
   int lpg = 1;
-  while (lpg < ppg && lpg * 2 * groups * qpb <= 1024) lpg <<= 1;
+  while (lpg < ppg && lpg * 2 * groups * qpb <= cap) lpg <<= 1;
   int nthreads = qpb * lpg * groups;
   nthreads = (nthreads + 63) & ~63;
   if (nthreads > 1024) nthreads = 1024;
