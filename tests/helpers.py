@@ -76,3 +76,42 @@ def assert_close_l2(a, b, tol, what=""):
     assert a.shape == b.shape, (what, tuple(a.shape), tuple(b.shape))
     num, den = float((a - b).norm()), float(b.norm()) + 1e-30
     assert num <= tol * den, "%s: relative L2 error %.3e > %.1e" % (what, num / den, tol)
+
+
+def make_cub_tree(root, n=14, dim=8):
+    """A small synthetic CUB-200-2011 tree in the layout the reference's BirdsDataset reads (datasets.py:424-433, 504-526;
+    embedding pickle as Audio_to_Image/extract_audio_feature.py:93-94 writes it).  Deterministic: tests/golden/
+    make_golden_datasets.py ran the REFERENCE's dataset on exactly this tree to produce tests/golden/datasets_cub.json.
+    The boxes cover the crop rule's branches: fractional coordinates (truncated to int), a box larger than the image
+    (clipped on all four sides), boxes touching a border, and a tiny box (radius floor of 10)."""
+    import json
+    import pickle
+    from PIL import Image
+    rng = np.random.RandomState(7)
+    img_root = os.path.join(root, "images")
+    boxes = [(10.0, 20.0, 50.0, 40.0), (0.0, 0.0, 30.0, 60.0), (55.5, 31.25, 41.75, 18.5), (3.0, 70.0, 120.0, 35.0),
+             (40.0, 40.0, 4.0, 6.0), (60.0, 5.0, 200.0, 300.0), (1.9, 2.9, 12.1, 12.9), (80.0, 90.0, 25.0, 11.0)]
+    items, box_lines, name_lines = [], [], []
+    for i in range(n):
+        cls = "%03d.Bird_%d" % (i % 4 + 1, i % 4)
+        rel = "%s/img_%d.png" % (cls, i)
+        os.makedirs(os.path.join(img_root, os.path.dirname(rel)), exist_ok=True)
+        w, h = 97 + 11 * i, 131 - 4 * i
+        Image.fromarray(rng.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(os.path.join(img_root, rel))
+        items.append({"image": rel, "class": cls, "audio": ["a_%d_%d.wav" % (i, k) for k in range(10)], "text": ["t"] * 10})
+        b = boxes[i % len(boxes)]
+        box_lines.append("%d %s %s %s %s\n" % ((i + 1,) + tuple(repr(v) for v in b)))
+        name_lines.append("%d %s\n" % (i + 1, rel))
+    for split in ("train", "test"):
+        with open(os.path.join(root, split + ".json"), "w") as fp:
+            json.dump({"image_base_path": img_root, "audio_base_path": os.path.join(root, "audio"), "data": items}, fp)
+        emb = rng.randn(n, 10, dim).astype(np.float32)
+        os.makedirs(os.path.join(root, split), exist_ok=True)
+        with open(os.path.join(root, split, "audio_features_image.pickle"), "wb") as fp:
+            pickle.dump(emb, fp)
+    os.makedirs(os.path.join(root, "CUB_200_2011"), exist_ok=True)
+    with open(os.path.join(root, "CUB_200_2011", "bounding_boxes.txt"), "w") as fp:
+        fp.writelines(box_lines)
+    with open(os.path.join(root, "CUB_200_2011", "images.txt"), "w") as fp:
+        fp.writelines(name_lines)
+    return items

@@ -1,9 +1,10 @@
 """on-disk formats at the edges of the step (reference StackGAN_v2/datasets.py:420-642,
 Audio_to_Image/extract_audio_feature.py:88-96, main.py:126-181).
 
-The reference's datasets need torchvision (absent here), so this row cannot be run side by side with the reference:
-parity is pinned on the deterministic arithmetic (crop box, resize sizes, normalisation, pickle layout, item tuple
-layout); the random crop/flip draws are "parity unpinned".
+The reference's transforms need torchvision (absent here).  The torchvision-free half -- load_bbox, the bounding-box crop,
+the item tuples and the `random` draws -- is pinned on a fixture the reference's own BirdsDataset produced
+(tests/golden/datasets_cub.json, make_golden_datasets.py); the resize / random-crop / flip / normalise half is pinned on its
+deterministic arithmetic only and stays "parity unpinned" against the reference.
 """
 import json
 import os
@@ -214,3 +215,55 @@ def test_places_subset_labels_and_paths(tmp_path):
     real, wrong, e, path, label = ds[1]
     assert path == "kitchenette/1.png" and label == 5 and e.shape == (8,) and real[2].shape == (3, 256, 256)
     assert [ds._get_class(it) for it in ds.json_data] == [0, 5, 6, 0]
+
+
+def test_birds_dataset_against_the_reference_fixture(tmp_path):
+    """tests/golden/datasets_cub.json holds what the REFERENCE's BirdsDataset returned on the tree of
+    helpers.make_cub_tree (make_golden_datasets.py: load_bbox, the bounding-box crop inside its get_imgs, the item tuples
+    and the `random` draws; datasets.py:40-52, 424-433, 456-499, 504-564).  Same tree, same seeds, this package's dataset:
+    every box, path, label, embedding row and cropped image must be identical.  The torchvision transforms are not part of
+    the fixture (absent library): transform = None and the crop is compared as the PIL image it is."""
+    import hashlib
+    from helpers import make_cub_tree
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "datasets_cub.json")) as fp:
+        gold = json.load(fp)
+    saved = cfg.TREE.BRANCH_NUM
+    cfg.TREE.BRANCH_NUM = 1
+    try:
+        make_cub_tree(str(tmp_path))
+        emb = D.load_embedding_pickle(str(tmp_path / "train" / "audio_features_image.pickle"))
+
+        def digest(img):
+            return {"size": [img.size[0], img.size[1]],
+                    "sha1": hashlib.sha1(np.asarray(img, dtype=np.uint8).tobytes()).hexdigest()}
+
+        ds = D.BirdsDataset(str(tmp_path), train=True, base_size=64, transform=None)
+        ds.norm = lambda img: img
+        assert len(ds) == gold["len"]
+        assert ds.bbox == gold["bbox"]
+        it = iter(gold["train_items"])
+        for seed in gold["seeds"]:
+            random.seed(seed)
+            for idx in range(len(ds)):
+                g = next(it)
+                real, wrong, e, path, label = ds[idx]
+                assert (g["seed"], g["index"]) == (seed, idx)
+                assert path == g["path"] and label == g["label"]
+                assert np.array_equal(e, emb[idx][g["emb_row"]])
+                assert digest(real[0]) == g["real"], (seed, idx)
+                assert digest(wrong[0]) == g["wrong"], (seed, idx)
+        ts = D.BirdsDataset(str(tmp_path), train=False, base_size=64, transform=None)
+        ts.norm = lambda img: img
+        for g in gold["test_items"]:
+            real, e, path = ts[g["index"]]
+            assert path == g["path"] and e.shape[0] == 10 and digest(real[0]) == g["real"]
+        random.seed(11)
+        draws = [ds.find_wrong_image(ds._get_class(ds.json_data[i % len(ds)])) for i in range(40)]
+        assert draws == gold["wrong_draws"]
+        # the crop rule alone on the fixture's boxes: sizes follow crop_box (datasets.py:43-52)
+        for g in (x for x in gold["train_items"] if x["seed"] == gold["seeds"][0]):
+            w, h = Image.open(os.path.join(ds.image_folder, g["path"])).size
+            x1, y1, x2, y2 = D.crop_box(gold["bbox"][g["path"][:-4]], w, h)
+            assert [x2 - x1, y2 - y1] == g["real"]["size"]
+    finally:
+        cfg.TREE.BRANCH_NUM = saved
