@@ -1757,14 +1757,19 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
 // LDS as it is, and a stage is 64 pixels deep (4 k-steps, 16 MFMAs per wave between two barriers instead of 8).
 // A32: the gathered operand is the fp32 NHWC4 image of the first discriminator conv (4x4 stride 2): 8 consecutive K columns
 // are two horizontally adjacent taps x 4 channels = 32 contiguous bytes, converted to bf16 while they are staged.
+// 256 x 128 tiles (8 waves, two blocks per CU; round 3): a tile of BM x BN moves (BM + BN) * 2 bytes per pixel from L2 into LDS
+// for 2 * BM * BN FLOP -- 64 FLOP/B at 128 x 128, which at the ~70 GB/s a CU takes from L2 (MI355X_MICROARCH.md, gather into
+// LDS) caps the chip near 0.65 PFLOP/s, where the 128 x 128 form sat (profiles/r03_roofline_bf16_wgrad_b48); 85 FLOP/B here.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A32 = false>
-__global__ __launch_bounds__(256, 3) void igemm_wgrad_b16_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 : 3)) void igemm_wgrad_b16_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
+  constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int PC = 64;                               // pixels per stage
   constexpr int AROWB = BM * 2, BROWB = BN * 2;
   constexpr int AMASK = BM / 8 - 1, BMASK = BN / 8 - 1;
   constexpr int ATPR = BM / 8, BTPR = BN / 8;          // threads per pixel row
-  constexpr int AROWS = 256 / ATPR, BROWS = 256 / BTPR;  // pixel rows per pass
+  constexpr int AROWS = NT / ATPR, BROWS = NT / BTPR;  // pixel rows per pass
+  static_assert(AROWS * ATPR == NT && BROWS * BTPR == NT && PC % AROWS == 0, "a pass covers whole pixel rows");
   constexpr int APASS = PC / AROWS, BPASS = (PC + BROWS - 1) / BROWS;
   __shared__ __attribute__((aligned(16))) unsigned char smem[PC * (AROWB + BROWB)];
   unsigned char* As = smem;
@@ -2376,6 +2381,7 @@ struct WgPlan {
   int T, K, Cin, Ho, Wo, M, tile, gridK, gridN, nchunks, splitk, cps, small_n, rows3, bn3;
 };
 
+// planes: 0 fp32 operands, 1..3 split-bf16 products (or one operand bf16), 16 both operands stored as bf16
 int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
   S2I_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->N > 0, "wgrad: non-positive extent");
   S2I_REQUIRE((d->Ca % 4) == 0 && (d->Cc % 4) == 0 && (d->N % 4) == 0 && d->Ca + d->Cc > 0,
@@ -2430,6 +2436,36 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
   }
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+  if (planes == 16 && pl->tile == 0 && (pl->K % 256) == 0 && (pl->Cin % 8) == 0 && d->Cc == 0 && (d->N % 8) == 0 &&
+      (d->ldg % 8) == 0 && s2i_tune(S2I_TUNE_WGRAD16_BM, 0) != 128) {
+    // both operands bf16: 256 x 128 tiles on 512-thread blocks, two per CU (512 slots), 64-pixel stages -- where that is
+    // cheaper than the 128 x 128 plan above under one model for both (us; measured on the config-4 layers,
+    // tools/wgrad16_bench.py: a round of 64-pixel stages takes ~2.5 us with 768 blocks of 128 x 128 and ~2.7 us with 512
+    // blocks of 256 x 128; a block's prologue / epilogue is worth 3 resp. 2 stages; each split writes and re-reads a slab)
+    const int nch64 = s2i_cdiv(M, 64);
+    const double slab_us = 2.0e-6 * (double)pl->K * d->N;
+    const int cps128 = s2i_cdiv(nch64, pl->splitk), se128 = s2i_cdiv(nch64, cps128);
+    const double cost128 = (double)((tiles * se128 + 767) / 768) * (cps128 + 3.0) * 2.5 + slab_us * se128;
+    const long long t2 = (long long)(pl->K / 256) * pl->gridN;
+    int smax = nch64 / 4, best_s = 1;
+    if (smax > 256) smax = 256;
+    if (smax < 1) smax = 1;
+    double best = 1e300;
+    for (int sc = 1; sc <= smax; ++sc) {
+      const int cps = s2i_cdiv(nch64, sc), se = s2i_cdiv(nch64, cps);
+      if (se != sc) continue;
+      const double cost = (double)((t2 * se + 511) / 512) * (cps + 2.0) * 2.7 + slab_us * se;
+      if (cost < best) { best = cost; best_s = se; }
+      if (t2 * sc > 4 * 512) break;
+    }
+    if (best < cost128 || s2i_tune(S2I_TUNE_WGRAD16_BM, 0) == 256) {
+      pl->tile = 6;
+      pl->gridK = pl->K / 256;
+      // kept in 32-pixel chunks like the other plans (the launcher re-derives the 64-pixel stages from splitk)
+      pl->cps = s2i_cdiv(pl->nchunks, best_s);
+      pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
+    }
+  }
   // thin 3x3 layers over wide maps: one kernel row per block, taps read from a staged row segment
   pl->rows3 = !planes && d->kind == S2I_CONV_K3S1 && d->Cc == 0 && (d->Ca == 32 || d->Ca == 64) && d->W >= 32 &&
               (d->N % 32) == 0 && d->N <= 128;
@@ -2830,7 +2866,7 @@ extern "C" int s2i_conv_wgrad_in(const s2i_wgrad_desc* d, const float* a_raw, co
 
 extern "C" size_t s2i_wgrad_workspace_bytes_dt(const s2i_wgrad_desc* d, int a_dtype, int g_dtype) {
   WgPlan pl;
-  if (plan_wgrad(d, &pl, (a_dtype || g_dtype) ? 1 : 0)) return 0;
+  if (plan_wgrad(d, &pl, (a_dtype && g_dtype) ? 16 : ((a_dtype || g_dtype) ? 1 : 0))) return 0;
   return (size_t)pl.splitk * pl.K * d->N * sizeof(float);
 }
 
@@ -2870,7 +2906,7 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
                            float* grad_oihw, void* ws, size_t ws_bytes, void* stream, int a16, int g16, const float* a_coef) {
   WgPlan pl;
   // bf16 operands: the plan of the split modes (no row-segment / 96-row tiles, which stage fp32 rows)
-  if (plan_wgrad(d, &pl, (planes || a16 || g16) ? 1 : 0)) return 1;
+  if (plan_wgrad(d, &pl, (a16 && g16) ? 16 : ((planes || a16 || g16) ? 1 : 0))) return 1;
   S2I_REQUIRE(!(planes && (a16 || g16)), "wgrad(split): bf16 tensors go through s2i_conv_wgrad_dt");
   S2I_REQUIRE(!(pl.small_n && g16), "wgrad: the <= 4 channel gradient stream expects an fp32 output gradient");
   S2I_REQUIRE((a || d->Ca == 0) && g && grad_oihw, "wgrad: null operand");
@@ -2918,7 +2954,8 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     S2I_REQUIRE((int)g16grid.z <= pl.splitk, "wgrad(bf16): split plan mismatch");
     // slabs of splits that this plan does not launch must not be summed: shrink the slab count instead
     pl.splitk = (int)g16grid.z;
-    if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 128, 2, 2>), g16grid, dim3(256), 0, st, q);
+    if (pl.tile == 6) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<256, 128, 4, 2>), g16grid, dim3(512), 0, st, q);
+    else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 128, 2, 2>), g16grid, dim3(256), 0, st, q);
     else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 64, 2, 2>), g16grid, dim3(256), 0, st, q);
     else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 32, 4, 1>), g16grid, dim3(256), 0, st, q);
     else hipLaunchKernelGGL((igemm_wgrad_b16_kernel<64, 64, 2, 2>), g16grid, dim3(256), 0, st, q);

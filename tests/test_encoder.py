@@ -101,8 +101,10 @@ def test_encoder_fallback_branches_against_oracle(gpu, B, bidirectional, nhidden
 
 
 @pytest.mark.gpu
-def test_config5_encoder_feeds_the_train_step(gpu):
-    """BASELINE config 5: CNNRNN.extract_feature at batch 24 on (24, 40, 2048) log-mel with n_frames in 640..2048 sorted
+@pytest.mark.parametrize("width", ["small3", "full3_fwd"], ids=["reduced_width", "full_width"])
+def test_config5_encoder_feeds_the_train_step(gpu, width):
+    """BASELINE config 5 (full_width: the GAN at cfg/birds_3stages.yml's own widths, i.e. the configuration as BASELINE.json
+    names it on one GPU): CNNRNN.extract_feature at batch 24 on (24, 40, 2048) log-mel with n_frames in 640..2048 sorted
     descending, cap_lens = n_frames // 64 (Audio_to_Image/speech_encoder.py:69-97, extract_audio_feature.py:25-57), feeding
     the StackGAN step.  The embedding is compared with the encoder oracle, the step's losses and images with the
     step oracle fed the ORACLE's embedding."""
@@ -120,7 +122,7 @@ def test_config5_encoder_feeds_the_train_step(gpu):
     cap_lens = n_frames // 64
     with torch.no_grad():
         _, sent_o = eorc.forward({k: v.clone() for k, v in enc.state_dict().items()}, mel, cap_lens, 512, True)
-    case = dict(CASES['small3'], t=1024, B=B)
+    case = dict(CASES[width], t=1024, B=B)
     netG, netsD = build_nets(case)
     batch = make_batch(case)
     batch['emb'] = sent_o.clone()
