@@ -1445,7 +1445,7 @@ __device__ __forceinline__ void wgrad_block_map(int& tile, int& split) {
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AACT = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 3) void igemm_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 : 3)) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM, LDB = BN;
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256, or 192 for the 96-row tiles (K = 9 * 32)
@@ -1760,8 +1760,10 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
 // 256 x 128 tiles (8 waves, two blocks per CU; round 3): a tile of BM x BN moves (BM + BN) * 2 bytes per pixel from L2 into LDS
 // for 2 * BM * BN FLOP -- 64 FLOP/B at 128 x 128, which at the ~70 GB/s a CU takes from L2 (MI355X_MICROARCH.md, gather into
 // LDS) caps the chip near 0.65 PFLOP/s, where the 128 x 128 form sat (profiles/r03_roofline_bf16_wgrad_b48); 85 FLOP/B here.
+// 256 x 256 tiles on 1024-thread blocks (one per CU) where N allows: 128 FLOP/B, 0.89 PFLOP/s on D_NET256's deep layers against
+// 0.80 (256 x 128) and 0.70 (128 x 128); two LDS stages with one barrier per stage measured the same and were removed.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A32 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 : 3)) void igemm_wgrad_b16_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 8 ? 1 : (WAVES_M * WAVES_N > 4 ? 2 : 3))) void igemm_wgrad_b16_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int PC = 64;                               // pixels per stage
@@ -1771,7 +1773,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 
   constexpr int AROWS = NT / ATPR, BROWS = NT / BTPR;  // pixel rows per pass
   static_assert(AROWS * ATPR == NT && BROWS * BTPR == NT && PC % AROWS == 0, "a pass covers whole pixel rows");
   constexpr int APASS = PC / AROWS, BPASS = (PC + BROWS - 1) / BROWS;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[PC * (AROWB + BROWB)];
+  constexpr int STAGE_BYTES = PC * (AROWB + BROWB);
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES];
   unsigned char* As = smem;
   unsigned char* Bs = smem + PC * AROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1854,35 +1857,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 
 
   const int c_begin = split * p.cps;
   const int c_end = min(p.nchunks, c_begin + p.cps);
-  if (c_begin < c_end) fetch(c_begin);
-  for (int pc = c_begin; pc < c_end; ++pc) {
+  auto stage_store = [&](unsigned char* A_, unsigned char* B_) {
 #pragma unroll
     for (int q = 0; q < APASS; ++q) {
       const int row = arow + q * AROWS;
       const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
-      *reinterpret_cast<u32x4*>(As + row * AROWB + 16 * ((acol8 ^ sw) & AMASK)) = ra[q];
+      *reinterpret_cast<u32x4*>(A_ + row * AROWB + 16 * ((acol8 ^ sw) & AMASK)) = ra[q];
     }
 #pragma unroll
     for (int q = 0; q < BPASS; ++q) {
       const int row = brow + q * BROWS;
       const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
-      if (row < PC) *reinterpret_cast<u32x4*>(Bs + row * BROWB + 16 * ((bcol8 ^ sw) & BMASK)) = rb[q];
+      if (row < PC) *reinterpret_cast<u32x4*>(B_ + row * BROWB + 16 * ((bcol8 ^ sw) & BMASK)) = rb[q];
     }
-    __syncthreads();
-    if (pc + 1 < c_end) fetch(pc + 1);
+  };
+  auto stage_mma = [&](const unsigned char* A_, const unsigned char* B_) {
 #pragma unroll
     for (int ks = 0; ks < PC / 16; ++ks) {
       bf16x8 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const s16x4 lo = lds_tr_read(As + ks * 16 * AROWB + aad[i][0]);
-        const s16x4 hi = lds_tr_read(As + ks * 16 * AROWB + aad[i][1]);
+        const s16x4 lo = lds_tr_read(A_ + ks * 16 * AROWB + aad[i][0]);
+        const s16x4 hi = lds_tr_read(A_ + ks * 16 * AROWB + aad[i][1]);
         a[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const s16x4 lo = lds_tr_read(Bs + ks * 16 * BROWB + bad[j][0]);
-        const s16x4 hi = lds_tr_read(Bs + ks * 16 * BROWB + bad[j][1]);
+        const s16x4 lo = lds_tr_read(B_ + ks * 16 * BROWB + bad[j][0]);
+        const s16x4 hi = lds_tr_read(B_ + ks * 16 * BROWB + bad[j][1]);
         b[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       }
 #pragma unroll
@@ -1891,6 +1893,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (int pc = c_begin; pc < c_end; ++pc) {
+    stage_store(As, Bs);
+    __syncthreads();
+    if (pc + 1 < c_end) fetch(pc + 1);
+    stage_mma(As, Bs);
     __syncthreads();
   }
 
@@ -2434,6 +2443,32 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
       if (tiles * sc > 4 * 768) break;
     }
   }
+  if (!planes && pl->tile == 0 && (pl->K % 256) == 0 && !d->a_act && s2i_tune(S2I_TUNE_WGRAD_BM, 0) != 128) {
+    // fp32 256 x 128 tiles on 512-thread blocks (two per CU, 512 slots): half the `g` re-reads of the 128 x 128 form; a round
+    // of chunks takes 1.26x as long for 1.33x the work (8.3 us against 6.6: tools/wgrad_bench.py, 103 -> 119 TFLOP/s on
+    // D_NET256's first stacked weight gradient).  Taken where the same cost model prices it lower.
+    const long long t2 = (long long)(pl->K / 256) * pl->gridN;
+    int smax = pl->nchunks / 4, s8 = 1;
+    if (smax > 256) smax = 256;
+    if (smax < 1) smax = 1;
+    double best8 = 1e300, cost0 = 1e300;
+    for (int sc = 1; sc <= smax; ++sc) {
+      const int cps = s2i_cdiv(pl->nchunks, sc), se = s2i_cdiv(pl->nchunks, cps);
+      if (se != sc) continue;
+      const double cost = (double)((t2 * se + 511) / 512) * (cps + 3.0) * 1.26 + 3.0e-7 * se * (double)pl->K * d->N;
+      if (cost < best8) { best8 = cost; s8 = se; }
+      if (t2 * sc > 4 * 512) break;
+    }
+    {
+      const int cps = s2i_cdiv(pl->nchunks, splitk), se = s2i_cdiv(pl->nchunks, cps);
+      cost0 = (double)((tiles * se + 767) / 768) * (cps + 3.0) + 3.0e-7 * se * (double)pl->K * d->N;
+    }
+    if (best8 < cost0 || s2i_tune(S2I_TUNE_WGRAD_BM, 0) == 256) {
+      pl->tile = 8;
+      pl->gridK = pl->K / 256;
+      splitk = s8;
+    }
+  }
   pl->cps = s2i_cdiv(pl->nchunks, splitk);
   pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
   if (planes == 16 && pl->tile == 0 && (pl->K % 256) == 0 && (pl->Cin % 8) == 0 && d->Cc == 0 && (d->N % 8) == 0 &&
@@ -2458,11 +2493,34 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
       if (cost < best) { best = cost; best_s = se; }
       if (t2 * sc > 4 * 512) break;
     }
-    if (best < cost128 || s2i_tune(S2I_TUNE_WGRAD16_BM, 0) == 256) {
-      pl->tile = 6;
+    // 256 x 256 tiles, one 1024-thread block per CU (256 slots), where 256 divides N: ~2.15 us per round of stages
+    int best3_s = 1;
+    double best3 = 1e300;
+    if ((d->N % 256) == 0) {
+      const long long t3 = (long long)(pl->K / 256) * (d->N / 256);
+      for (int sc = 1; sc <= smax; ++sc) {
+        const int cps = s2i_cdiv(nch64, sc), se = s2i_cdiv(nch64, cps);
+        if (se != sc) continue;
+        const double cost = (double)((t3 * se + 255) / 256) * (cps + 3.0) * 2.15 + slab_us * se;
+        if (cost < best3) { best3 = cost; best3_s = se; }
+        if (t3 * sc > 4 * 256) break;
+      }
+    }
+    const int force = s2i_tune(S2I_TUNE_WGRAD16_BM, 0);   // 0 model, 128 / 256 / 512 (= 256 x 256) forced where eligible
+    int pick = 0;
+    if (force == 512 && best3 < 1e300) pick = 7;
+    else if (force == 256 || force == 512) pick = 6;
+    else if (force == 0) {
+      const double m = best3 < best ? best3 : best;
+      if (m < cost128) pick = best3 < best ? 7 : 6;
+    }
+    if (pick) {
+      const int bs = pick == 7 ? best3_s : best_s;
+      pl->tile = pick;
       pl->gridK = pl->K / 256;
+      if (pick == 7) pl->gridN = d->N / 256;
       // kept in 32-pixel chunks like the other plans (the launcher re-derives the 64-pixel stages from splitk)
-      pl->cps = s2i_cdiv(pl->nchunks, best_s);
+      pl->cps = s2i_cdiv(pl->nchunks, bs);
       pl->splitk = s2i_cdiv(pl->nchunks, pl->cps);
     }
   }
@@ -2954,7 +3012,8 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     S2I_REQUIRE((int)g16grid.z <= pl.splitk, "wgrad(bf16): split plan mismatch");
     // slabs of splits that this plan does not launch must not be summed: shrink the slab count instead
     pl.splitk = (int)g16grid.z;
-    if (pl.tile == 6) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<256, 128, 4, 2>), g16grid, dim3(512), 0, st, q);
+    if (pl.tile == 7) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<256, 256, 4, 4>), g16grid, dim3(1024), 0, st, q);
+    else if (pl.tile == 6) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<256, 128, 4, 2>), g16grid, dim3(512), 0, st, q);
     else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 128, 2, 2>), g16grid, dim3(256), 0, st, q);
     else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 64, 2, 2>), g16grid, dim3(256), 0, st, q);
     else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_b16_kernel<128, 32, 4, 1>), g16grid, dim3(256), 0, st, q);
@@ -2975,7 +3034,8 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(small_n_wgrad_kernel<16>, dim3(pl.splitk), dim3(256), 0, st, p);
-  } else if (pl.tile == 0 && a_coef) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
+  } else if (pl.tile == 8) hipLaunchKernelGGL((igemm_wgrad_kernel<256, 128, 4, 2>), grid, dim3(512), 0, st, p);
+  else if (pl.tile == 0 && a_coef) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 2) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 32, 4, 1>), grid, dim3(256), 0, st, p);

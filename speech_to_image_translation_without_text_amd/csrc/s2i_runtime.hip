@@ -30,7 +30,7 @@ extern "C" int s2i_check_device(void) {
 // ---- tuning knobs ----------------------------------------------------------------------------------------------------
 #include <stdlib.h>
 static const char* const g_tune_names[S2I_TUNE_COUNT] = {"fwd_bm", "fwd_min_cps", "b16_v2", "b16_persist", "finalize_threads", "b16_dbg",
-                                                            "wgrad16_bm"};
+                                                            "wgrad16_bm", "wgrad_bm"};
 static int g_tune_val[S2I_TUNE_COUNT];
 static bool g_tune_set[S2I_TUNE_COUNT];
 

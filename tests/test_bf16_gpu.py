@@ -108,9 +108,9 @@ def test_bf16_conv_kernels_against_fp32_on_rounded_operands(gpu, case):
     _conv_case(gpu, case)
 
 
-@pytest.mark.parametrize("bm", [128, 256])
+@pytest.mark.parametrize("bm", [128, 256, 512])
 @pytest.mark.parametrize("case", [("k4s2", 2, 64, 64, 128), ("k3s1", 5, 4, 256, 512), ("k4s2", 9, 16, 64, 128),
-                                  ("up", 2, 32, 64, 128)], ids=lambda c: "-".join(str(v) for v in c))
+                                  ("up", 2, 32, 64, 128), ("k4s2", 3, 32, 128, 256)], ids=lambda c: "-".join(str(v) for v in c))
 def test_bf16_weight_gradient_tile_heights(gpu, case, bm):
     """igemm_wgrad_b16_kernel with 128 x 128 and with 256 x 128 tiles (wgrad16_bm forces either wherever 256 divides the taps x
     channels rows; the planner otherwise picks by its cost model): same reference, same bounds."""

@@ -28,7 +28,7 @@ CASES = [
     ("G joint k3 192->128 @64 (B)", CONV_K3S1, (B, 64, 64, 192), (B, 64, 64, 128), (128, 192, 3, 3)),
 ]
 which = sys.argv[2:] or None
-tot = {128: 0.0, 256: 0.0, 0: 0.0}
+tot = {128: 0.0, 256: 0.0, 0: 0.0, 512: 0.0}
 for name, kind, ashape, gshape, wshape in CASES:
     if which and not any(w in name for w in which):
         continue
@@ -39,7 +39,7 @@ for name, kind, ashape, gshape, wshape in CASES:
     T = wshape[2] * wshape[3]
     M = gshape[0] * gshape[1] * gshape[2]
     flops = 2.0 * M * wshape[0] * wshape[1] * T
-    for bm in (128, 256, 0):
+    for bm in (128, 256, 0) + ((512,) if os.environ.get('TRY512') else ()):
         with _lib.tuning(wgrad16_bm=bm):
             out = torch.zeros(wshape, device=dev)
             fn = lambda: ops.wgrad_any(kind, a, g, wshape, out=out)
