@@ -1444,8 +1444,9 @@ __device__ __forceinline__ void wgrad_block_map(int& tile, int& split) {
   tile = Ll / in_group;
 }
 
+// (HIP's second launch bound is waves per SIMD: 3 = three 256-thread blocks per CU, 4 = two 512-thread blocks or one of 1024)
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool AACT = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 2 : 3)) void igemm_wgrad_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 4 : 3)) void igemm_wgrad_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int LDA = BM, LDB = BN;
   constexpr int NT = 64 * WAVES_M * WAVES_N;  // 256, or 192 for the 96-row tiles (K = 9 * 32)
@@ -1763,7 +1764,7 @@ __global__ __launch_bounds__(256, 3) void igemm_wgrad_split_kernel(WgradP p) {
 // 256 x 256 tiles on 1024-thread blocks (one per CU) where N allows: 128 FLOP/B, 0.89 PFLOP/s on D_NET256's deep layers against
 // 0.80 (256 x 128) and 0.70 (128 x 128); two LDS stages with one barrier per stage measured the same and were removed.
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool A32 = false>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 8 ? 1 : (WAVES_M * WAVES_N > 4 ? 2 : 3))) void igemm_wgrad_b16_kernel(WgradP p) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N > 4 ? 4 : 3)) void igemm_wgrad_b16_kernel(WgradP p) {
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
   constexpr int NT = 64 * WAVES_M * WAVES_N;
   constexpr int PC = 64;                               // pixels per stage

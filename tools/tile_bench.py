@@ -36,7 +36,8 @@ for kind, xs, N, wmode in CASES:
     Mout = xs[0] * xs[1] * xs[2] * (4 if kind == TC else 1) // (4 if kind == K4 else 1)
     flops = 2.0 * Mout * N * Tg * Cx
     line = "%-5s x%-22s N%-5d wm%d " % (NAME[kind], list(xs), N, wmode)
-    for rows in (128, 96, 0):
+    best_ms = {}
+    for rows in (128, 96, 0, 128, 96, 0):      # two alternating passes, the better one counts (the first runs cold)
         ops.TILE_ROWS = rows
         fn = lambda: ops.conv_raw(kind, x, None, packed, N, wmode=wmode, wR=packed.shape[1], ldw=packed.shape[2],
                                   stats=(wmode == 0))
@@ -49,6 +50,9 @@ for kind, xs, N, wmode in CASES:
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
+        best_ms[rows] = min(ms, best_ms.get(rows, 1e9))
+    for rows in (128, 96, 0):
+        ms = best_ms[rows]
         tot[rows] += ms
         line += " | %3d: %6.3f ms %6.1f TF" % (rows, ms, flops / ms / 1e9)
     ops.TILE_ROWS = 0
