@@ -154,3 +154,32 @@ def test_tuning_knobs_roundtrip_without_a_gpu():
     assert lib.s2i_conv_stat_parts(ctypes.byref(big)) == 72 * 32 * 32 // 96      # the stacked passes take 96-row tiles
     big.tile_rows = 128
     assert lib.s2i_conv_stat_parts(ctypes.byref(big)) == 72 * 32 * 32 // 128
+
+
+def test_weight_gradient_planner_tile_heights_without_a_gpu():
+    """The weight-gradient planner's three bf16 tile shapes and two fp32 ones (s2i_igemm.hip::plan_wgrad) through the
+    workspace query: every plan asks for a whole number of K x N fp32 slabs, a forced shape is honoured only where 256
+    divides the taps x channels rows (and, for 256 x 256, the output channels), and the cost model picks the large tiles on
+    D_NET256's stacked stride-2 layers."""
+    import ctypes
+    from speech_to_image_translation_without_text_amd import _lib
+    lib = _lib.load()
+    BF16 = 1
+
+    def slabs(d, dt, **knobs):
+        with _lib.tuning(**knobs):
+            n = lib.s2i_wgrad_workspace_bytes_dt(ctypes.byref(d), dt, dt)
+        kn = (16 if d.kind == _lib.CONV_K4S2 else 9) * d.Ca * d.N * 4
+        assert n > 0 and n % kn == 0, (n, kn)
+        return n // kn
+
+    # D_NET256 conv3 over the stacked batch of config 4: a (144,64,64,128), g (144,32,32,256)
+    d = _lib.WgradDesc(_lib.CONV_K4S2, 144, 64, 64, 128, 0, 256, 256, 0, 0, 256, 128, 4, 4, 1, 0, 0, 0, 0)
+    s128, s256, s512, s0 = (slabs(d, BF16, wgrad16_bm=v) for v in (128, 256, 512, 0))
+    # K = 2048 rows x 256 columns: 32 / 16 / 8 tiles; tiles x splits fill the chip's 768 / 512 / 256 block slots
+    assert 700 <= s128 * 32 <= 1600 and 400 <= s256 * 16 <= 1100 and 200 <= s512 * 8 <= 600, (s128, s256, s512)
+    assert s0 in (s256, s512)                                                     # the model leaves 128 x 128 here
+    assert slabs(d, 0, wgrad_bm=256) != 0 and slabs(d, 0, wgrad_bm=0) in (slabs(d, 0, wgrad_bm=256), slabs(d, 0, wgrad_bm=128))
+    # 3x3, 64 -> 128 channels: 576 rows, 256 does not divide them: every setting plans the same 128-row tiles
+    e = _lib.WgradDesc(_lib.CONV_K3S1, 48, 64, 64, 64, 0, 128, 128, 0, 0, 128, 64, 3, 3, 1, 0, 0, 0, 0)
+    assert len({slabs(e, BF16, wgrad16_bm=v) for v in (0, 128, 256, 512)}) == 1

@@ -70,3 +70,24 @@ for regime in ("sync each step", "run ahead"):
                            ("step", "f0", "g1")):
             acc.setdefault(name, []).append(e[a].elapsed_time(e[b]))
     print("%s: %.2f ms/step wall | " % (regime, wall) + "  ".join("%s %.2f" % (k, sum(v) / len(v)) for k, v in acc.items()), flush=True)
+
+# every piece replayed ALONE (nothing else on the chip): how long its chain is without contention.  If the discriminator
+# phase of the step (fwd end -> G start) is close to the longest chain alone, the phase is bound by that chain's latency; if it
+# is close to the SUM of the three, by the chip's throughput.
+alone = {}
+for name, plan, stream in (("G forward", pl['fwd'][0], main), ("D64 piece", pl['d'][0][0], sides[0]),
+                           ("D128 piece", pl['d'][1][0], sides[1]), ("D256 piece", pl['d'][2][0], sides[2]),
+                           ("G piece", pl['g'][0], main)):
+    ts = []
+    for k in range(6):
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record(stream)
+        lib.s2i_plan_replay(plan, stream.cuda_stream)
+        b.record(stream)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    alone[name] = sum(ts[2:]) / len(ts[2:])
+print("alone: " + "  ".join("%s %.2f" % kv for kv in alone.items()) +
+      "  | sum of the D pieces %.2f, longest %.2f" % (alone["D64 piece"] + alone["D128 piece"] + alone["D256 piece"],
+                                                       max(alone["D64 piece"], alone["D128 piece"], alone["D256 piece"])), flush=True)
