@@ -339,7 +339,7 @@ def test_bf16_step_small_net_tracks_fp32(gpu):
     c = _run_steps(gpu, case, 1, True)
     print("small3 bf16 vs fp32 losses", a['losses'], c['losses'])
     for la, lc in zip(a['losses'][0], c['losses'][0]):
-        assert abs(la - lc) <= 0.03 * abs(la) + 2e-3, (a['losses'], c['losses'])
+        assert abs(la - lc) <= 0.01 * abs(la) + 2e-3, (a['losses'], c['losses'])
     for i in range(3):
         r = rel_l2(c['fakes'][i], a['fakes'][i])
         print("small3 img%d: rel L2 %.3e, max abs %.3e" % (i, r, float((c['fakes'][i] - a['fakes'][i]).abs().max())))
@@ -350,20 +350,21 @@ def test_bf16_config4_full_width_batch48_tracks_fp32(gpu):
     """BASELINE config 4 at its workload: branch_num=3, full width, batch 48, bf16 activations.  One full iteration
     (G forward, three D updates, G update with lr_G = 0 so that G's gradients stay readable) in bf16 mode against the
     fp32 HIP path on the same seeded weights and inputs.  Reports max-abs and relative-L2 deviation of the images, the
-    losses and G's gradients and bounds them: images 3e-2 rel L2, losses 3 %, G gradients
-    (which pass three discriminators that each side updated itself, in bf16 vs fp32) 0.25 rel L2 for the large tensors."""
+    losses and G's gradients and bounds them at about 1.5 - 2x what is measured (round 3: images
+    8.4e-3 rel L2 / 3.7e-2 max abs, losses 0.1 %, end-to-end G gradients 0.33, segments G 2.2e-2, D 8.5e-2 / 1.2e-1 / 1.5e-1): images
+    1.5e-2 / 8e-2, losses 1 %, end to end 0.45, segments 3e-2 and 1.2e-1 / 1.6e-1 / 2e-1."""
     case = dict(CASES['full3_fwd'], B=48)
     a = _run_steps(gpu, case, 1, False)
     torch.cuda.empty_cache()
     c = _run_steps(gpu, case, 1, True)
     print("config 4 (B=48) losses fp32 %s | bf16 %s" % (a['losses'][0], c['losses'][0]))
     for la, lc in zip(a['losses'][0], c['losses'][0]):
-        assert abs(la - lc) <= 0.03 * abs(la) + 2e-3, (a['losses'], c['losses'])
+        assert abs(la - lc) <= 0.01 * abs(la) + 2e-3, (a['losses'], c['losses'])
     for i in range(3):
         r = rel_l2(c['fakes'][i], a['fakes'][i])
         mx = float((c['fakes'][i] - a['fakes'][i]).abs().max())
         print("config 4 img%d (%dpx): rel L2 %.3e, max abs %.3e" % (i, 64 << i, r, mx))
-        assert r < 3e-2 and mx < 0.25, (i, r, mx)
+        assert r < 1.5e-2 and mx < 8e-2, (i, r, mx)
     # end to end G's gradients pass three discriminators that each side updated itself (first-step Adam = lr * sign(g))
     # and their LeakyReLU chains: reported, loosely bounded; the segments below carry the real bounds
     worst = ("", 0.0)
@@ -373,7 +374,7 @@ def test_bf16_config4_full_width_batch48_tracks_fp32(gpu):
             worst = (k, r)
     print("config 4 G gradients END TO END: worst rel L2 deviation over tensors >= 4096 elements: %s %.3e; grad_emb %.3e"
           % (worst[0], worst[1], rel_l2(c['grad_emb'], a['grad_emb'])))
-    assert worst[1] < 0.6, worst
+    assert worst[1] < 0.45, worst
     del a, c
     torch.cuda.empty_cache()
     sa = _segment_grads(gpu, case, False)
@@ -381,7 +382,7 @@ def test_bf16_config4_full_width_batch48_tracks_fp32(gpu):
     sc = _segment_grads(gpu, case, True)
     # D: every LeakyReLU decides its slope from a bf16-rounded pre-activation, ~0.1 % of the decisions differ from the fp32
     # path per layer (2.5e-2 of the gradient norm per layer, test_bf16_fused_block...), up to eight layers deep
-    for seg, tol in (("G", 4e-2), ("D0", 2e-1), ("D1", 2e-1), ("D2", 2e-1)):
+    for seg, tol in (("G", 3e-2), ("D0", 1.2e-1), ("D1", 1.6e-1), ("D2", 2e-1)):
         worst = ("", 0.0)
         for k, gref in sa[seg].items():
             r = rel_l2(sc[seg][k], gref)
