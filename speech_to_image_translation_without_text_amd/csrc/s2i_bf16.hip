@@ -963,6 +963,8 @@ __device__ __forceinline__ int src_tap(int kind, int flip, int T, int t, int pha
   return flip ? (T - 1 - t) : t;
 }
 
+constexpr int PACK16_KT = 4;   // 32 x 32 tiles per block of the batched re-pack (even)
+
 __device__ __forceinline__ void pack_bf16_block(const float* __restrict__ P, unsigned short* __restrict__ out, int R, int C,
                                                 int kind, int flip, int transpose, int T, int Nn, int Npad, int Kk,
                                                 int CK, int bx, int by, int zt, float (&tile)[32][33]) {
@@ -1005,6 +1007,76 @@ __device__ __forceinline__ void pack_bf16_block(const float* __restrict__ P, uns
   }
 }
 
+// PACK16_KT tiles of 32 x 32 in one block, side by side along the SOURCE-contiguous dimension (n for the forward layout, k for
+// the transposed one): all loads of the strip are issued before the one barrier (16 in flight per thread instead of 4), and a
+// source row contributes 512 contiguous bytes to a block instead of 128 (round 3: D_NET256's re-pack 283 -> 237 us with the
+// tiles walked one after another, -> see profiles/README.md for this form).
+__device__ __forceinline__ void pack_bf16_strip(const s2i_pack16_item& it, int bx, int by, int zt,
+                                                float (&tile)[PACK16_KT][33][33]) {   // 33 x 33: tile i starts one bank later
+  const int T = it.T, C = it.C, Kk = it.Kk, Nn = it.Nn, Npad = it.Npad, CK = it.CK;
+  const int phase = zt / T, t = zt - phase * T;
+  const int ts = src_tap(it.kind, it.flip, T, t, phase);
+  const float* sp = it.P + (size_t)ts * it.R * C;
+  // 16-byte loads: a strip row is PACK16_KT * 32 floats = 32 lanes x 4; eight rows per pass, four passes
+  static_assert(PACK16_KT == 4, "a strip row is covered by 32 lanes of four floats");
+  const int c4 = threadIdx.x & 31, r8 = threadIdx.x >> 5;
+  const int i = c4 >> 3, cl = (c4 & 7) * 4;          // tile of the strip, first of the lane's four columns inside it
+  const bool vec_ok = (C & 3) == 0 && ((size_t)sp & 15) == 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rl = r8 + 8 * q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!it.transpose) {
+      const int k = by * 32 + rl, n = (bx * PACK16_KT) * 32 + c4 * 4;      // P[k][n .. n + 3]
+      if (k < Kk && n < Nn) {
+        const float* src = sp + (size_t)k * C + n;
+        if (vec_ok && n + 3 < C) v = *reinterpret_cast<const f32x4*>(src);
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (n + j < C) v[j] = src[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n + j >= Nn) v[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[i][rl][cl + j] = v[j];
+    } else {
+      const int n = bx * 32 + rl, k = (by * PACK16_KT) * 32 + c4 * 4;      // P[n][k .. k + 3]
+      if (n < Nn && k < Kk) {
+        const float* src = sp + (size_t)n * C + k;
+        if (vec_ok && k + 3 < C) v = *reinterpret_cast<const f32x4*>(src);
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (k + j < C) v[j] = src[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k + j >= Kk) v[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[i][cl + j][rl] = v[j];
+    }
+  }
+  __syncthreads();
+  const int half = threadIdx.x >> 7, w = threadIdx.x & 127;
+  const int nl = w >> 2, sg = w & 3;
+  const int nchunk = Kk / CK;
+#pragma unroll
+  for (int j = 0; j < PACK16_KT / 2; ++j) {
+    const int i = 2 * j + half;
+    const int n0 = (it.transpose ? bx : bx * PACK16_KT + i) * 32, k0 = (it.transpose ? by * PACK16_KT + i : by) * 32;
+    const int n = n0 + nl, k = k0 + sg * 8;
+    if (n < Npad && k < Kk) {
+      const int cc = k / CK, kc = k - cc * CK;
+      u32x4 v;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        f32x2 f = {tile[i][sg * 8 + 2 * h][nl], tile[i][sg * 8 + 2 * h + 1][nl]};
+        v[h] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+      }
+      const size_t o = ((((size_t)phase * nchunk + cc) * T + t) * Npad + n) * CK + kc;
+      *reinterpret_cast<u32x4*>(it.out + o) = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ P, unsigned short* __restrict__ out, int R,
                                                         int C, int kind, int flip, int transpose, int T, int nphase,
                                                         int Nn, int Npad, int Kk, int CK) {
@@ -1015,7 +1087,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
 // every bf16 weight copy of a network in ONE launch (after the fused Adam): item k owns the linear blocks
 // [block0, block0 + gx * gy * nphase * T), block0 ascending
 __global__ __launch_bounds__(256) void pack_bf16_batched_kernel(const s2i_pack16_item* __restrict__ items, int n) {
-  __shared__ float tile[32][33];
+  __shared__ float tile[PACK16_KT][33][33];
   const int b = blockIdx.x;
   int lo = 0, hi = n - 1;
   while (lo < hi) {                       // last item with block0 <= b
@@ -1025,9 +1097,8 @@ __global__ __launch_bounds__(256) void pack_bf16_batched_kernel(const s2i_pack16
   }
   const s2i_pack16_item it = items[lo];
   const int r = b - it.block0;
-  const int bx = r % it.gx, by = (r / it.gx) % it.gy, zt = r / (it.gx * it.gy);
-  pack_bf16_block(it.P, it.out, it.R, it.C, it.kind, it.flip, it.transpose, it.T, it.Nn, it.Npad, it.Kk, it.CK, bx, by, zt,
-                  tile);
+  const int bx = r % it.gx, by = (r / it.gx) % it.gy, zt = r / (it.gx * it.gy);   // it.gx / it.gy count STRIPS
+  pack_bf16_strip(it, bx, by, zt, tile);
 }
 
 // ---- split-K reduction with bf16 output (+ BatchNorm column statistics), as splitk_reduce_stats_kernel -----------------
@@ -1349,7 +1420,10 @@ extern "C" int s2i_pack16_item_fill(const s2i_conv_desc* d, const float* packed,
   else S2I_REQUIRE(R >= Kk && C >= Nn, "pack(bf16): P is %d x %d, need rows >= %d cols >= %d", R, C, Kk, Nn);
   item->P = packed; item->out = out; item->R = R; item->C = C; item->kind = pl.kb; item->flip = d->flip;
   item->transpose = transpose; item->T = pl.T; item->nphase = pl.nphases; item->Nn = Nn; item->Npad = pl.Npad;
-  item->Kk = Kk; item->CK = pl.CK; item->gx = pl.Npad / 32; item->gy = Kk / 32; item->block0 = 0;
+  item->Kk = Kk; item->CK = pl.CK; item->block0 = 0;
+  // strips of PACK16_KT tiles along the source-contiguous dimension (pack_bf16_strip)
+  item->gx = transpose ? pl.Npad / 32 : (pl.Npad / 32 + PACK16_KT - 1) / PACK16_KT;
+  item->gy = transpose ? (Kk / 32 + PACK16_KT - 1) / PACK16_KT : Kk / 32;
   return item->gx * item->gy * pl.nphases * pl.T;   // blocks of this item
 }
 
