@@ -2225,51 +2225,89 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   }
 }
 
-// OIHW -> packed P[t][Ip][Op] through an LDS tile of 32 cout x 8 cin x taps: coalesced on both sides.
-__device__ __forceinline__ void pack_tile(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int Tp,
+// OIHW -> packed P[t][Ip][Op] through an LDS tile of 64 cout x 8 cin x taps.  Round 3: 64 instead of 32 output channels per
+// tile (a packed row segment is 256 contiguous bytes), 16-byte accesses on both sides where the shape allows, the tap count a
+// template parameter (no integer division by a runtime value per element).  D_NET256's re-pack: see profiles/README.md.
+template <int TP>   // taps of the parameter (16, 9, or 0 = any: scalar accesses)
+__device__ __forceinline__ void pack_tile(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int Tp_rt,
                                           int Ip, int Op, int T, int mode, int bx, int by, float* tile) {
+  const int Tp = TP ? TP : Tp_rt;
   const int tid = threadIdx.x;
-  const int o0 = bx * 32, i0 = by * 8;
+  const int o0 = bx * 64, i0 = by * 8;
   const int ostride = 8 * Tp + 1;
-  const int nload = 32 * 8 * Tp;
-  for (int e = tid; e < nload; e += 256) {
-    const int tapo = e % Tp;
-    const int i_l = (e / Tp) & 7;
-    const int o_l = e / (Tp * 8);
-    const int o = o0 + o_l, i = i0 + i_l;
-    tile[o_l * ostride + i_l * Tp + tapo] = (o < O && i < I) ? w[((size_t)o * I + i) * Tp + tapo] : 0.f;
+  if (TP && (I & 3) == 0 && (((size_t)w) & 15) == 0) {
+    // a row of the tile is 8 * TP contiguous floats of w (2 * TP float4); i0 is a multiple of 8 and I of 4: 16-byte aligned
+    constexpr int F4 = 2 * (TP ? TP : 1);
+    for (int e = tid; e < 64 * F4; e += 256) {
+      const int o_l = e / F4, f = e - o_l * F4;
+      const int o = o0 + o_l;
+      const int i_first = i0 + (f * 4) / Tp;            // cin of the first of the four floats
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (o < O && i_first < I) {
+        const size_t off = ((size_t)o * I + i0) * Tp + f * 4;
+        if (((size_t)o * I + i0) * Tp + f * 4 + 3 < (size_t)(o + 1) * I * Tp) v = *reinterpret_cast<const f32x4*>(w + off);
+        else
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (off + j < (size_t)(o + 1) * I * Tp) v[j] = w[off + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[o_l * ostride + f * 4 + j] = v[j];
+    }
+  } else {
+    const int nload = 64 * 8 * Tp;
+    for (int e = tid; e < nload; e += 256) {
+      const int tapo = e % Tp;
+      const int i_l = (e / Tp) & 7;
+      const int o_l = e / (Tp * 8);
+      const int o = o0 + o_l, i = i0 + i_l;
+      tile[o_l * ostride + i_l * Tp + tapo] = (o < O && i < I) ? w[((size_t)o * I + i) * Tp + tapo] : 0.f;
+    }
   }
   __syncthreads();
-  const int nout = T * 8 * 32;
+  // (t, i) rows of 64 output channels = 16 float4
+  const int nout = T * 8 * 16;
   for (int e = tid; e < nout; e += 256) {
-    const int o_l = e & 31;
-    const int i_l = (e >> 5) & 7;
-    const int t = e >> 8;
-    const int o = o0 + o_l, i = i0 + i_l;
+    const int o4 = e & 15;
+    const int i_l = (e >> 4) & 7;
+    const int t = e >> 7;
+    const int o = o0 + o4 * 4, i = i0 + i_l;
     if (o >= Op || i >= Ip) continue;
-    const float* tp = tile + o_l * ostride + i_l * Tp;
-    float v = 0.f;
-    if (mode == S2I_PACK_UPFOLD) {
-      // effective tap k4 sums parameter taps: 0:{2} 1:{1,2} 2:{0,1} 3:{0}
-      const int k4y = t >> 2, k4x = t & 3;
-      const int ylo = k4y == 0 ? 2 : (k4y == 1 ? 1 : 0), yhi = k4y == 0 ? 2 : (k4y == 1 ? 2 : (k4y == 2 ? 1 : 0));
-      const int xlo = k4x == 0 ? 2 : (k4x == 1 ? 1 : 0), xhi = k4x == 0 ? 2 : (k4x == 1 ? 2 : (k4x == 2 ? 1 : 0));
-      for (int ky = ylo; ky <= yhi; ++ky)
-        for (int kx = xlo; kx <= xhi; ++kx) v += tp[ky * 3 + kx];
-    } else {
-      v = tp[t];
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float* tp = tile + (o4 * 4 + j) * ostride + i_l * Tp;
+      float x = 0.f;
+      if (mode == S2I_PACK_UPFOLD) {
+        // effective tap k4 sums parameter taps: 0:{2} 1:{1,2} 2:{0,1} 3:{0}
+        const int k4y = t >> 2, k4x = t & 3;
+        const int ylo = k4y == 0 ? 2 : (k4y == 1 ? 1 : 0), yhi = k4y == 0 ? 2 : (k4y == 1 ? 2 : (k4y == 2 ? 1 : 0));
+        const int xlo = k4x == 0 ? 2 : (k4x == 1 ? 1 : 0), xhi = k4x == 0 ? 2 : (k4x == 1 ? 2 : (k4x == 2 ? 1 : 0));
+        for (int ky = ylo; ky <= yhi; ++ky)
+          for (int kx = xlo; kx <= xhi; ++kx) x += tp[ky * 3 + kx];
+      } else {
+        x = tp[t];
+      }
+      v[j] = x;
     }
-    packed[((size_t)t * Ip + i) * Op + o] = v;
+    *reinterpret_cast<f32x4*>(packed + ((size_t)t * Ip + i) * Op + o) = v;   // Op is a multiple of 4 and so is o
   }
+}
+
+__device__ __forceinline__ void pack_tile_any(const float* __restrict__ w, float* __restrict__ packed, int O, int I, int Tp,
+                                              int Ip, int Op, int T, int mode, int bx, int by, float* tile) {
+  if (Tp == 16) pack_tile<16>(w, packed, O, I, Tp, Ip, Op, T, mode, bx, by, tile);
+  else if (Tp == 9) pack_tile<9>(w, packed, O, I, Tp, Ip, Op, T, mode, bx, by, tile);
+  else pack_tile<0>(w, packed, O, I, Tp, Ip, Op, T, mode, bx, by, tile);
 }
 
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ packed,
                                                           int O, int I, int Tp, int Ip, int Op, int T, int mode) {
-  extern __shared__ float tile[];  // [32][8*Tp + 1]
-  pack_tile(w, packed, O, I, Tp, Ip, Op, T, mode, blockIdx.x, blockIdx.y, tile);
+  extern __shared__ float tile[];  // [64][8*Tp + 1]
+  pack_tile_any(w, packed, O, I, Tp, Ip, Op, T, mode, blockIdx.x, blockIdx.y, tile);
 }
 
-// every conv weight of one network in ONE launch (after the fused Adam step): the table lives in device memory
+// every conv weight of one network in ONE launch (after the fused Adam step): the table lives in device memory; item.gx
+// counts 64-channel tiles
 __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const s2i_pack_item* __restrict__ items, int n) {
   extern __shared__ float tile[];
   int k = 0;
@@ -2277,8 +2315,8 @@ __global__ __launch_bounds__(256) void pack_weight_batched_kernel(const s2i_pack
   const s2i_pack_item it = items[k];
   const int local = blockIdx.x - it.block0;
   const int T = it.mode == S2I_PACK_UPFOLD ? 16 : it.KH * it.KW;
-  pack_tile(it.w, it.packed, it.O, it.I, it.KH * it.KW, it.Ip, (it.O + 3) & ~3, T, it.mode, local % it.gx, local / it.gx,
-            tile);
+  pack_tile_any(it.w, it.packed, it.O, it.I, it.KH * it.KW, it.Ip, (it.O + 3) & ~3, T, it.mode, local % it.gx, local / it.gx,
+                tile);
 }
 
 // ---- host-side planning ------------------------------------------------------------------------
@@ -3077,7 +3115,7 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
 extern "C" int s2i_pack_conv_weights_batched(const s2i_pack_item* items_dev, int n, int total_blocks, int max_taps,
                                              void* stream) {
   S2I_REQUIRE(items_dev && n > 0 && total_blocks > 0 && max_taps > 0 && max_taps <= 16, "pack(batched): bad args");
-  const size_t shb = (size_t)32 * (8 * max_taps + 1) * sizeof(float);
+  const size_t shb = (size_t)64 * (8 * max_taps + 1) * sizeof(float);
   hipLaunchKernelGGL(pack_weight_batched_kernel, dim3(total_blocks), dim3(256), shb, (hipStream_t)stream, items_dev, n);
   S2I_LAUNCH_CHECK("pack_weight_batched");
   return 0;
@@ -3096,8 +3134,8 @@ extern "C" int s2i_pack_conv_weight(const float* w_oihw, float* packed, int O, i
   }
   const int Op = (O + 3) & ~3;
   {
-    dim3 pgrid(s2i_cdiv(Op, 32), s2i_cdiv(Ip, 8));
-    const size_t shb = (size_t)32 * (8 * KH * KW + 1) * sizeof(float);
+    dim3 pgrid(s2i_cdiv(Op, 64), s2i_cdiv(Ip, 8));
+    const size_t shb = (size_t)64 * (8 * KH * KW + 1) * sizeof(float);
     hipLaunchKernelGGL(pack_weight_kernel, pgrid, dim3(256), shb, (hipStream_t)stream, w_oihw, packed, O, I, KH * KW,
                        Ip, Op, T, mode);
   }

@@ -162,7 +162,7 @@ def refresh_packed(params):
             else:
                 O, I, KH, KW = p.shape
             Ip, Op = _roundup4(I), _roundup4(O)
-            gx = (Op + 31) // 32
+            gx = (Op + 63) // 64          # 64-channel tiles (csrc/s2i_igemm.hip::pack_tile)
             items[k] = _lib.PackItem(p.data_ptr(), out.data_ptr(), O, I, KH, KW, Ip, mode, gx, block0)
             block0 += gx * ((Ip + 7) // 8)
             max_taps = max(max_taps, KH * KW)
