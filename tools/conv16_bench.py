@@ -16,6 +16,9 @@ LAYERS = [
     ("D256 s64 fwd", CONV_K4S2, 3 * B, 8, 1024, 2048, 0), ("D256 s64_1 fwd", CONV_K3S1, 3 * B, 4, 2048, 1024, 0),
     ("D256 conv3 dgrad", TCONV_K4S2, 3 * B, 32, 256, 128, 1), ("D256 conv2 dgrad", TCONV_K4S2, 3 * B, 64, 128, 64, 1),
     ("D256 conv4 dgrad", TCONV_K4S2, 3 * B, 16, 512, 256, 1),
+    ("D256 s32 dgrad", TCONV_K4S2, 3 * B, 8, 1024, 512, 1), ("D256 s64 dgrad", TCONV_K4S2, 3 * B, 4, 2048, 1024, 1),
+    ("D256 s64_1 dgrad", CONV_K3S1, 3 * B, 4, 1024, 2048, 1), ("D256 s64 fwd (G pass)", CONV_K4S2, B, 8, 1024, 2048, 0),
+    ("D256 s32 fwd (G pass)", CONV_K4S2, B, 16, 512, 1024, 0), ("D128 s32 fwd", CONV_K4S2, 3 * B, 8, 512, 1024, 0),
     ("G h2 res conv fwd", CONV_K3S1, B, 64, 64, 128, 0), ("G h2 res conv2 fwd", CONV_K3S1, B, 64, 64, 64, 0),
     ("G h3 res conv fwd", CONV_K3S1, B, 128, 32, 64, 0), ("G h3 res conv2 fwd", CONV_K3S1, B, 128, 32, 32, 0),
     ("G h3 up fwd", TCONV_K4S2, B, 128, 32, 32, 0), ("G h2 up fwd", TCONV_K4S2, B, 64, 64, 64, 0),
