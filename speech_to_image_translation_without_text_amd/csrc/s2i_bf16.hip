@@ -1245,6 +1245,28 @@ int plan_bf16(const s2i_conv_desc* d, BPlan* pl) {
     if (splitk > 32) splitk = 32;
     if (splitk < 1) splitk = 1;
   }
+  if (!pl->v2 && pl->nchunk >= 4 && !d->nosplit && blocks < 4 * slots) {
+    // 128-pixel kernel, a launch of a few blocks per CU: the time is set by the CU that holds one block more than the others
+    // (the discriminators' 8 -> 4 px layer at batch 48: 288 blocks on 256 CUs ran like 512).  Price every split by the work
+    // of the most loaded CU plus the slab traffic it adds, in us: a CU does ~3.9 TFLOP/s with two resident blocks (0.6 of its
+    // clocked bf16 peak, profiles/r03_bf16_conv_layers.txt), ~0.75 of that with one; slabs move at ~4 TB/s; the reduction is a
+    // launch of its own (~12 us in its chain).
+    const double tile_us = 2.0 * 128.0 * pl->BN * (double)pl->T * d->Cx / 3.9e6;
+    const double slab_us = (double)pl->Mrows * d->N * 8.0 / 4.0e6;
+    double best = 1e300;
+    int best_s = splitk;
+    const int smax = pl->nchunk / 2 < 32 ? pl->nchunk / 2 : 32;
+    for (int sc = 1; sc <= smax; ++sc) {
+      const int cps = s2i_cdiv(pl->nchunk, sc), se = s2i_cdiv(pl->nchunk, cps);
+      if (se != sc) continue;
+      const long long nb = blocks * se;
+      const double per_cu = (double)((nb + 255) / 256);
+      double cost = per_cu / se * tile_us * (nb <= 256 ? 1.0 / 0.75 : 1.0) + 2.5 * per_cu;   // + a block's prologue / epilogue
+      if (se > 1) cost += se * slab_us + 12.0;
+      if (cost < best) { best = cost; best_s = se; }
+    }
+    splitk = best_s;
+  }
   pl->cps = s2i_cdiv(pl->nchunk, splitk);
   pl->splitk = s2i_cdiv(pl->nchunk, pl->cps);
   return 0;
