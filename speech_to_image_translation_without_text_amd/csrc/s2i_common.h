@@ -44,7 +44,7 @@ enum {
   S2I_TUNE_FINALIZE_THREADS, // finalize_threads: thread cap of a BatchNorm finalize block (default 256)
   S2I_TUNE_B16_DBG,         // b16_dbg: diagnostic instantiation of the bf16 convolution kernels (libs2i_hip_diag.so only)
   S2I_TUNE_WGRAD16_BM,      // wgrad16_bm: tile height of the bf16 weight-gradient kernel where 256 divides K (0 = cost model, 128, 256, 512 = 256 x 256)
-  S2I_TUNE_WGRAD_BM,        // wgrad_bm: tile height of the fp32 weight-gradient kernel where 256 divides K (0 = cost model, 128, 256)
+  S2I_TUNE_WGRAD_BM,        // wgrad_bm: tile of the fp32 weight-gradient kernel where 256 divides K (0 = cost model, 1 = model without 256 x 256, 128, 256, 512 = 256 x 256)
   S2I_TUNE_COUNT
 };
 int s2i_tune(int key, int def);

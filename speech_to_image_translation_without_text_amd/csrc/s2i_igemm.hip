@@ -2502,7 +2502,27 @@ int plan_wgrad(const s2i_wgrad_desc* d, WgPlan* pl, int planes = 0) {
       const int cps = s2i_cdiv(pl->nchunks, splitk), se = s2i_cdiv(pl->nchunks, cps);
       cost0 = (double)((tiles * se + 767) / 768) * (cps + 3.0) + 3.0e-7 * se * (double)pl->K * d->N;
     }
-    if (best8 < cost0 || s2i_tune(S2I_TUNE_WGRAD_BM, 0) == 256) {
+    // 256 x 256 tiles on one 1024-thread block per CU (256 slots) where 256 divides N: a round of chunks takes 1.22x the
+    // 128 x 128 round for 1.33x the work (D_NET256's three middle layers 0.650 -> 0.628 ms, profiles/r03_f32_wgrad_tile_heights.txt)
+    int s9 = 1;
+    double best9 = 1e300;
+    if ((d->N % 256) == 0) {
+      const long long t3 = (long long)(pl->K / 256) * (d->N / 256);
+      for (int sc = 1; sc <= smax; ++sc) {
+        const int cps = s2i_cdiv(pl->nchunks, sc), se = s2i_cdiv(pl->nchunks, cps);
+        if (se != sc) continue;
+        const double cost = (double)((t3 * se + 255) / 256) * (cps + 3.0) * 1.22 + 3.0e-7 * se * (double)pl->K * d->N;
+        if (cost < best9) { best9 = cost; s9 = se; }
+        if (t3 * sc > 4 * 256) break;
+      }
+    }
+    const int force = s2i_tune(S2I_TUNE_WGRAD_BM, 0);   // 0 model, 128 / 256 / 512 (= 256 x 256) forced where eligible
+    if ((force == 512 && best9 < 1e300) || (force == 0 && best9 < best8 && best9 < cost0)) {
+      pl->tile = 9;
+      pl->gridK = pl->K / 256;
+      pl->gridN = d->N / 256;
+      splitk = s9;
+    } else if (best8 < cost0 || force == 256 || force == 512) {
       pl->tile = 8;
       pl->gridK = pl->K / 256;
       splitk = s8;
@@ -3073,7 +3093,8 @@ static int conv_wgrad_impl(const s2i_wgrad_desc* d, int planes, const float* a, 
     if (d->Ca == 16) hipLaunchKernelGGL(small_n_wgrad_kernel<4>, dim3(pl.splitk), dim3(256), 0, st, p);
     else if (d->Ca == 32) hipLaunchKernelGGL(small_n_wgrad_kernel<8>, dim3(pl.splitk), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(small_n_wgrad_kernel<16>, dim3(pl.splitk), dim3(256), 0, st, p);
-  } else if (pl.tile == 8) hipLaunchKernelGGL((igemm_wgrad_kernel<256, 128, 4, 2>), grid, dim3(512), 0, st, p);
+  } else if (pl.tile == 9) hipLaunchKernelGGL((igemm_wgrad_kernel<256, 256, 4, 4>), grid, dim3(1024), 0, st, p);
+  else if (pl.tile == 8) hipLaunchKernelGGL((igemm_wgrad_kernel<256, 128, 4, 2>), grid, dim3(512), 0, st, p);
   else if (pl.tile == 0 && a_coef) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 2, 2>), grid, dim3(256), 0, st, p);
   else if (pl.tile == 1) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 2, 2>), grid, dim3(256), 0, st, p);

@@ -179,7 +179,8 @@ def test_weight_gradient_planner_tile_heights_without_a_gpu():
     # K = 2048 rows x 256 columns: 32 / 16 / 8 tiles; tiles x splits fill the chip's 768 / 512 / 256 block slots
     assert 700 <= s128 * 32 <= 1600 and 400 <= s256 * 16 <= 1100 and 200 <= s512 * 8 <= 600, (s128, s256, s512)
     assert s0 in (s256, s512)                                                     # the model leaves 128 x 128 here
-    assert slabs(d, 0, wgrad_bm=256) != 0 and slabs(d, 0, wgrad_bm=0) in (slabs(d, 0, wgrad_bm=256), slabs(d, 0, wgrad_bm=128))
+    f = {v: slabs(d, 0, wgrad_bm=v) for v in (128, 256, 512, 0)}
+    assert 700 <= f[128] * 32 <= 1600 and 400 <= f[256] * 16 <= 1100 and 200 <= f[512] * 8 <= 600 and f[0] in (f[256], f[512]), f
     # 3x3, 64 -> 128 channels: 576 rows, 256 does not divide them: every setting plans the same 128-row tiles
     e = _lib.WgradDesc(_lib.CONV_K3S1, 48, 64, 64, 64, 0, 128, 128, 0, 0, 128, 64, 3, 3, 1, 0, 0, 0, 0)
     assert len({slabs(e, BF16, wgrad16_bm=v) for v in (0, 128, 256, 512)}) == 1

@@ -203,6 +203,42 @@ def test_tile_rows_96_equals_128(gpu, case):
         close(outs[1][1].float(), outs[0][1].float(), rtol=1e-5, atol=1e-5, what="column sums")
 
 
+WGRAD_TILES = [
+    # kind, B, H, Cin, Cout      (taps x Cin a multiple of 256; the last two also have 256 | Cout)
+    ("k4s2", 3, 32, 64, 128),
+    ("k4s2", 5, 16, 128, 256),
+    ("k3s1", 6, 8, 256, 512),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_TILES, ids=lambda c: "-".join(str(v) for v in c))
+def test_weight_gradient_tile_shapes_against_torch(gpu, case):
+    """igemm_wgrad_kernel with 128 x 128, 256 x 128 (512 threads) and 256 x 256 (1024 threads) tiles -- wgrad_bm forces each where
+    the shape allows, 0 lets the planner's cost model choose -- against torch's fp32 weight gradient."""
+    import torch.nn.functional as F
+    from speech_to_image_translation_without_text_amd import _lib, ops
+    from speech_to_image_translation_without_text_amd._lib import CONV_K3S1, CONV_K4S2
+    kind, B, H, Cin, Cout = case
+    g = torch.Generator().manual_seed(5)
+    kk = 4 if kind == "k4s2" else 3
+    Ho = H // 2 if kind == "k4s2" else H
+    x = torch.randn(B, Cin, H, H, generator=g)
+    gy = torch.randn(B, Cout, Ho, Ho, generator=g)
+    w = torch.zeros(Cout, Cin, kk, kk, requires_grad=True)
+    (F.conv2d(x, w, stride=2 if kind == "k4s2" else 1, padding=1) * gy).sum().backward()
+    a = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    gg = gy.permute(0, 2, 3, 1).contiguous().to(gpu)
+    results = {}
+    for bm in (128, 256, 512, 0):
+        with _lib.tuning(wgrad_bm=bm):
+            out = ops.wgrad_raw(CONV_K4S2 if kind == "k4s2" else CONV_K3S1, a, None, gg, (Cout, Cin, kk, kk))
+        torch.cuda.synchronize()
+        results[bm] = out.cpu()
+        close(out.cpu(), w.grad, rtol=1e-3, atol=1e-3 * float(w.grad.abs().max()), what="dW (wgrad_bm=%d)" % bm)
+    # one pixel order per output element whatever the tile: the shapes differ only in how the pixel range is split
+    close(results[256], results[128], rtol=1e-4, atol=1e-4 * float(w.grad.abs().max()), what="256 x 128 against 128 x 128")
+
+
 CONVACT = [
     # kind, B, H, Cin(true), Cin padded, Cout(true), n_out, act, bias
     ("k4s2", 2, 16, 3, 4, 16, 16, "lrelu", False),   # first D conv on an NHWC4 image
