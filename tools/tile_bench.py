@@ -26,7 +26,8 @@ CASES = [
 ]
 NAME = {K4: "k4s2", K3: "k3s1", TC: "tconv"}
 reps = int(os.environ.get("REPS", "10"))
-tot = {128: 0.0, 96: 0.0, 0: 0.0}
+ROWS = tuple(int(v) for v in os.environ.get("ROWS", "128,96,0").split(","))
+tot = {r: 0.0 for r in ROWS}
 for kind, xs, N, wmode in CASES:
     x = torch.randn(xs, device=dev)
     T = {K3: 9, K4: 16, TC: 16}[kind]
@@ -37,7 +38,7 @@ for kind, xs, N, wmode in CASES:
     flops = 2.0 * Mout * N * Tg * Cx
     line = "%-5s x%-22s N%-5d wm%d " % (NAME[kind], list(xs), N, wmode)
     best_ms = {}
-    for rows in (128, 96, 0, 128, 96, 0):      # two alternating passes, the better one counts (the first runs cold)
+    for rows in ROWS + ROWS:      # two alternating passes, the better one counts (the first runs cold)
         ops.TILE_ROWS = rows
         fn = lambda: ops.conv_raw(kind, x, None, packed, N, wmode=wmode, wR=packed.shape[1], ldw=packed.shape[2],
                                   stats=(wmode == 0))
@@ -51,10 +52,10 @@ for kind, xs, N, wmode in CASES:
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         best_ms[rows] = min(ms, best_ms.get(rows, 1e9))
-    for rows in (128, 96, 0):
+    for rows in ROWS:
         ms = best_ms[rows]
         tot[rows] += ms
         line += " | %3d: %6.3f ms %6.1f TF" % (rows, ms, flops / ms / 1e9)
     ops.TILE_ROWS = 0
     print(line, flush=True)
-print("sum: 128 rows %.2f ms, 96 rows %.2f ms, planner %.2f ms" % (tot[128], tot[96], tot[0]))
+print("sum: " + ", ".join("%s %.2f ms" % ("planner" if r == 0 else "%d rows" % r, tot[r]) for r in ROWS))
