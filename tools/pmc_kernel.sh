@@ -1,8 +1,8 @@
 #!/bin/bash
-# SQ counters of the dominant kernel (one rocprofv3 --pmc pass, no tracing).  usage: tools/pmc_kernel.sh <tag> <math> <batch> COUNTER...
+# SQ counters of the dominant kernel (one rocprofv3 --pmc pass, no tracing).  usage: [ROOFLINE_KERNEL=wgrad] tools/pmc_kernel.sh <tag> <math> <batch> COUNTER...
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; MATH=$2; B=$3; shift 3
 OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o p -- python3 $R/bench.py --roofline-only --math $MATH --batch $B > $OUT/run.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT -o p -- python3 $R/bench.py --roofline-only ${ROOFLINE_KERNEL:+--roofline-kernel $ROOFLINE_KERNEL} --math $MATH --batch $B > $OUT/run.log 2>&1
 echo "rc=$?"
 cd $R && python3 - <<PY
 import csv, glob, collections
